@@ -1,0 +1,191 @@
+/* edrl_hip.h — C-ABI of the MI355X-native EDRL hot path (libedrl_hip.so, gfx950).
+ *
+ * The reference (xinkunwang111/Robust-Multimodal-Learning-...-Disentangled-Representation) has no
+ * FFI/plugin layer: its hot path is `fusion_net.MedFusion.forward` + `MMD.MK_MMD` made of stock
+ * torch ops.  Each entry point below replaces one torch op site on that path;
+ * the reference site is cited per function (paths relative to the reference repo).
+ *
+ * Conventions
+ *  - plain device pointers and sizes only; no torch types; fp32 data; NHWC activations
+ *    ([rows][channels] with an explicit row/pixel stride `ld*` in elements where given).
+ *  - every function only enqueues work on `stream` and returns immediately:
+ *    0 = ok, >0 = hipError_t, <0 = argument error (-22 EINVAL, -28 workspace too small).
+ *  - kernels never allocate; outputs and workspaces are caller-owned (the Python host side
+ *    allocates them from the torch caching allocator).
+ *  - device scalars (losses and their upstream gradients) are passed as 1-element device
+ *    arrays so that nothing on this path synchronises with the host.
+ */
+#ifndef EDRL_HIP_H
+#define EDRL_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+/* flags of edrl_conv2d_nhwc_fwd_f32 / _dgrad_f32 */
+#define EDRL_FLAG_RELU 1   /* y = max(y, 0) after bias                     */
+#define EDRL_FLAG_ACCUM 2  /* y += previous contents of the destination     */
+
+/* ---- MFMA contractions (conv_gemm.hip) -------------------------------------------------
+ * Convolution forward; a Linear layer is the 1x1 case (N = rows, H = W = 1).
+ *   y = (relu?)(conv(x, w) + bias) * mul   [+ y]
+ * Replaces: encoder convs behind fusion_net.py:884-885 (absent Models/), nn.Linear at
+ * fusion_net.py:82-90 (EPRL.encoder, with the ReLU and the Dropout mask fused),
+ * :635-643 (DILR projectors), :555 (MHA in/out projections), :562-566 (FFN), :801-805
+ * (fc_fundus, fc), and the Gram matmul of code/MMD.py:26.
+ * x [N,Hi,Wi,Ci] (pixel stride ld_x), w [Co,KH,KW,Ci], bias [Co]|NULL,
+ * mul [N,Ho,Wo,Co]|NULL (pixel stride ld_aux), y [N,Ho,Wo,Co] (pixel stride ld_y). */
+int edrl_conv2d_nhwc_fwd_f32(const float* x, const float* w, const float* bias, const float* mul,
+                             float* y, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                             int KW, int stride, int pad, long ld_x, long ld_y, long ld_aux, int flags,
+                             hipStream_t stream);
+
+/* Data gradient (autograd of the above): dx [+]= conv_transpose(dy, w).
+ * wt is w permuted to [Ci,KH,KW,Co] by edrl_permute_weight_f32. */
+int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int Hi, int Wi, int Ci,
+                               int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, long ld_dy,
+                               long ld_dx, int flags, hipStream_t stream);
+
+/* Weight gradient: dw[Co,KH,KW,Ci] [+]= sum over pixels dy (x) x, split-K with an ordered
+ * (deterministic) reduction through `workspace`. */
+size_t edrl_conv2d_nhwc_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW);
+int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace,
+                               size_t workspace_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
+                               int Co, int KH, int KW, int stride, int pad, long ld_dy, long ld_x,
+                               int accumulate, hipStream_t stream);
+
+/* in [A][B][C] -> out [C][B][A]. */
+int edrl_permute_weight_f32(const float* in, float* out, int A, int B, int C, hipStream_t stream);
+
+/* ---- BatchNorm / pooling / layout (bn_pool.hip) -----------------------------------------
+ * Train-mode BatchNorm over rows of x [M][C]: batch statistics, running-stat update
+ * (momentum, unbiased variance), and the per-channel affine (scale, shift) that applies it.
+ * Replaces F.batch_norm(training=True) inside the encoders and DILR.bn1/bn2
+ * (fusion_net.py:653-654,658,757-758; gamma = beta = NULL for affine=False). */
+size_t edrl_bn_workspace_bytes(long M, int C);
+int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            float* save_mean, float* save_rstd, float* scale, float* shift, float* workspace,
+                            size_t workspace_bytes, hipStream_t stream);
+/* out = (relu?)(x*scale + shift [+ residual]) */
+int edrl_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
+                      long M, int C, long ld, int relu, hipStream_t stream);
+/* Backward of BN(+residual)(+ReLU).  dout = grad of the activated output, out = that output
+ * (NULL when no ReLU); dx = grad of the raw input; dres (optional) [+]= masked dout.
+ * workspace >= edrl_bn_workspace_bytes(M,C) + 2*C*4 bytes. */
+int edrl_bn_bwd_f32(const float* dout, const float* out, const float* x, const float* save_mean,
+                    const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, int accumulate,
+                    float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
+                    size_t workspace_bytes, hipStream_t stream);
+
+/* 3x3 / stride 2 / pad 1 max pooling on NHWC (encoder stem); idx = window tap of the first max. */
+int edrl_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C,
+                              hipStream_t stream);
+int edrl_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,
+                              hipStream_t stream);
+/* [N,C,H,W] -> [N,H,W,Cp], channels C..Cp-1 zero (loader layout of data_harvard.py:830-841). */
+int edrl_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t stream);
+/* out[a][d] = scale * sum_l in[a][l][d]  — global average pool; att.mean(dim=1) fusion_net.py:225;
+ * torch.mean(y_uni, dim=1) fusion_net.py:737-738; bias gradients. */
+int edrl_sum_axis1_f32(const float* in, float* out, long A, int L, int D, float scale, hipStream_t stream);
+/* out[a][l][d] [+]= scale * in[a][d]  — its backward; mu_proxy.repeat fusion_net.py:246-247. */
+int edrl_bcast_axis1_f32(const float* in, float* out, long A, int L, int D, float scale, int accumulate,
+                         hipStream_t stream);
+
+/* ---- head reductions (head_ops.hip) ---------------------------------------------------- */
+/* op codes of edrl_ew_f32 */
+#define EDRL_EW_RELU 0
+#define EDRL_EW_RELU_BWD 1
+#define EDRL_EW_AXPBY 2
+#define EDRL_EW_MUL 3
+#define EDRL_EW_SCALE 4
+#define EDRL_EW_SOFTPLUS 5
+#define EDRL_EW_SOFTPLUS_BWD 6
+#define EDRL_EW_MASKED_BWD 7
+#define EDRL_EW_ADD_RELU 8
+#define EDRL_EW_SCALE_BY_PTR 9
+#define EDRL_EW_FILL 10
+int edrl_ew_f32(int op, long n, const float* a, const float* b, const float* c, float* out, float alpha,
+                float beta, hipStream_t stream);
+/* out = sum_i w[i] * *in[i]  (n <= 8) — loss mixers fusion_net.py:870-879,942-948, fusion_train.py:212.
+ * `in` and `w` are HOST arrays (of device pointers / of weights). */
+int edrl_scalar_mix_f32(const float* const* in, const float* w, int n, float* out, hipStream_t stream);
+
+/* F.normalize over axis 1 of [A][L][D] (fusion_net.py:149-150). inv [A][D] saved for backward. */
+int edrl_l2norm_axis1_fwd_f32(const float* x, float* y, float* inv, long A, int L, int D, float eps,
+                              hipStream_t stream);
+int edrl_l2norm_axis1_bwd_f32(const float* dy, const float* y, const float* inv, float* dx, long A, int L, int D,
+                              hipStream_t stream);
+/* out[a][l][d] = u[a][d] + v[a][d]*w[a][l][d] (fusion_net.py:143-146, 907, 910) and its backward. */
+int edrl_affine_bcast_fwd_f32(const float* u, const float* v, const float* w, float* out, long A, int L, int D,
+                              hipStream_t stream);
+int edrl_affine_bcast_bwd_f32(const float* dout, const float* w, float* du, float* dv, long A, int L, int D,
+                              hipStream_t stream);
+
+/* Essence-point selection (fusion_net.py:227-243): positive = row of the label's proxy,
+ * negative = the remaining rows; top-K of each, loss = mean_b exp(neg_mean - pos_mean).
+ * att [B][C][S]; y int64 [B]; sel [B][C][S] (caller zeroes) marks the selected entries
+ * (bit-exact index set); means [B][2]; e [B]; loss [1]. */
+int edrl_topk_margin_fwd_f32(const float* att, const long long* y, unsigned char* sel, float* means, float* e,
+                             float* loss, int B, int C, int S, int K, hipStream_t stream);
+int edrl_topk_margin_bwd_f32(const float* dloss, const float* e, const unsigned char* sel, const long long* y,
+                             float* datt, int B, int C, int S, int K, hipStream_t stream);
+/* flag[0] |= 1 when a label is outside [0,C) (the reference raises KeyError, fusion_net.py:101,227). */
+int edrl_check_labels(const long long* y, int B, int C, int* flag, hipStream_t stream);
+
+/* PoE.forward for two experts (fusion_net.py:26-52), elementwise over R; workspace >= 128 floats. */
+int edrl_poe2_fwd_f32(const float* mu0, const float* s0, const float* mu1, const float* s1, const float* phi,
+                      float* out, long R, float eps, hipStream_t stream);
+int edrl_poe2_bwd_f32(const float* g, const float* mu0, const float* s0, const float* mu1, const float* s1,
+                      const float* phi, float* dmu0, float* ds0, float* dmu1, float* ds1, float* dphi,
+                      float* workspace, long R, float eps, hipStream_t stream);
+/* get_KL_loss / KL_between_normals vs N(0,1) (fusion_net.py:390-402,838-850); mu, sg [Bn][C][D];
+ * workspace >= 64 floats. */
+int edrl_kl_normal_fwd_f32(const float* mu, const float* sg, float* loss, float* workspace, long Bn, int C, int D,
+                           hipStream_t stream);
+int edrl_kl_normal_bwd_f32(const float* dloss, const float* mu, const float* sg, float* dmu, float* dsg, long Bn,
+                           int C, int D, hipStream_t stream);
+
+/* Inner attention of nn.MultiheadAttention(E, H) with head dim 128 (fusion_net.py:555,571):
+ * q [B][Lq][E] (projected), kv [B][N][2E] (projected keys | values), P [B][H][Lq][N], ctx [B][Lq][E]. */
+int edrl_mha_core_fwd_f32(const float* q, const float* kv, float* P, float* ctx, int B, int Lq, int N, int H, int E,
+                          hipStream_t stream);
+int edrl_mha_core_bwd_f32(const float* dctx, const float* q, const float* kv, const float* P, float* dq, float* dkv,
+                          int B, int Lq, int N, int H, int E, hipStream_t stream);
+
+/* nn.LayerNorm(E) over rows (fusion_net.py:560,573). */
+int edrl_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                           long R, int E, float eps, hipStream_t stream);
+int edrl_layernorm_bwd_f32(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                           float* dx, float* dw, float* db, long R, int E, hipStream_t stream);
+
+/* DILR.bt_loss_cross reductions (fusion_net.py:664-677) on the two diagonal blocks of c.
+ * out[7] = loss_c,on_c,off_c,loss_u,on_u,off_u,(loss_c+loss_u)/2; workspace >= 512 floats. */
+int edrl_bt_loss_fwd_f32(const float* cc, const float* cu, int n, float lambd, float* out, float* workspace,
+                         hipStream_t stream);
+int edrl_bt_loss_bwd_f32(const float* dloss12, const float* cc, const float* cu, float* dcc, float* dcu, int n,
+                         float lambd, hipStream_t stream);
+
+/* Label-smoothed cross entropy (fusion_net.py:931-939) and argmax (fusion_train.py:213). */
+int edrl_smooth_ce_fwd_f32(const float* pred, const long long* y, float* loss, int B, int C, float smoothing,
+                           hipStream_t stream);
+int edrl_smooth_ce_bwd_f32(const float* dloss, const float* pred, const long long* y, float* dpred, int B, int C,
+                           float smoothing, hipStream_t stream);
+int edrl_argmax_rows_f32(const float* x, long long* out, int B, int C, hipStream_t stream);
+
+/* ---- MK-MMD (mmd.hip; code/MMD.py:3-74) ------------------------------------------------- */
+int edrl_rowsq_f32(const float* x, float* sq, int n, int d, long ld, hipStream_t stream);
+/* G = total@total^T [n][n], sq [n]; loss [1]; saved [3] = {bandwidth, signed sum, loss}. */
+int edrl_mk_mmd_fwd_f32(const float* G, const float* sq, int n, int ns, float kernel_mul, int kernel_num, float* loss,
+                        float* saved, hipStream_t stream);
+/* coef [n][n] with dTotal = coef @ total; workspace n*n floats. */
+int edrl_mk_mmd_bwd_f32(const float* dloss, const float* G, const float* sq, const float* saved, int n, int ns,
+                        float kernel_mul, int kernel_num, float* workspace, float* coef, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDRL_HIP_H */

@@ -1,0 +1,72 @@
+"""CPU oracle for the build-owned encoders — TEST INFRASTRUCTURE ONLY.
+
+The reference's encoder sources are absent (`Models/` is not in the reference repository; call
+sites fusion_net.py:796,799,884-885), so parity for E1-E3 is *unpinned by the reference*: the oracle
+is the standard composition of torch CPU ops (F.conv2d, F.batch_norm(training=True), F.relu,
+F.max_pool2d, adaptive average pooling, F.linear) in the He et al. v1.5 ResNet topology, as
+SURVEY.md §8(c) prescribes.  It consumes the product's parameters by name (conv weights are stored
+[Co,KH,KW,Ci] by the product and permuted to torch's [Co,Ci,KH,KW] here).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _bn(x, sd, name, train=True):
+    rm = sd[name + ".running_mean"]
+    rv = sd[name + ".running_var"]
+    return F.batch_norm(x, rm, rv, sd[name + ".weight"], sd[name + ".bias"], train, 0.1, 1e-5)
+
+
+def _conv(x, sd, name, stride, pad):
+    w = sd[name + ".weight"].permute(0, 3, 1, 2)
+    return F.conv2d(x, w[:, :x.shape[1]], stride=stride, padding=pad)
+
+
+def trunk_forward(x, sd, kind, blocks, train=True):
+    """x NCHW -> feature map NCHW. `sd`: dict name -> tensor (parameters may require grad; running
+    stats are updated in place like nn.BatchNorm2d)."""
+    x = F.relu(_bn(_conv(x, sd, "conv1", 2, 3), sd, "bn1", train))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for blk in blocks:
+        pre, s = blk["name"], blk["stride"]
+        idn = x
+        if kind == "bottleneck":
+            o = F.relu(_bn(_conv(x, sd, pre + ".conv1", 1, 0), sd, pre + ".bn1", train))
+            o = F.relu(_bn(_conv(o, sd, pre + ".conv2", s, 1), sd, pre + ".bn2", train))
+            o = _bn(_conv(o, sd, pre + ".conv3", 1, 0), sd, pre + ".bn3", train)
+        else:
+            o = F.relu(_bn(_conv(x, sd, pre + ".conv1", s, 1), sd, pre + ".bn1", train))
+            o = _bn(_conv(o, sd, pre + ".conv2", 1, 1), sd, pre + ".bn2", train)
+        if blk["downsample"]:
+            idn = _bn(_conv(x, sd, pre + ".downsample.0", s, 0), sd, pre + ".downsample.1", train)
+        x = F.relu(o + idn)
+    return x
+
+
+def fundus_encoder_forward(x, sd, kind, blocks, proj_w, proj_b, train=True):
+    """[B,3,H,W] -> (tokens [B,N2,D], pooled)."""
+    f = trunk_forward(x, sd, kind, blocks, train)
+    B, C, h, w = f.shape
+    tok = f.permute(0, 2, 3, 1).reshape(B, h * w, C)
+    tokens = F.linear(tok, proj_w, proj_b)
+    return tokens, tokens.mean(1)
+
+
+def oct_encoder_forward(x, sd, kind, blocks, proj_w, proj_b, train=True):
+    """[B,1,S,H,W] -> (tokens [B,S,D], pooled)."""
+    B, C, S, H, W = x.shape
+    f = trunk_forward(x.reshape(B * S, 1, H, W), sd, kind, blocks, train)
+    pooled = f.mean(dim=(2, 3)).reshape(B, S, -1)
+    tokens = F.linear(pooled, proj_w, proj_b)
+    return tokens, tokens.mean(1)
+
+
+def trunk_state(trunk, dtype=torch.float64, requires_grad=True):
+    """Copy a product ResNetTrunk's parameters/buffers to CPU tensors keyed by dotted names."""
+    sd = {}
+    for n, p in trunk.named_parameters():
+        sd[n] = p.detach().cpu().to(dtype).requires_grad_(requires_grad)
+    for n, b in trunk.named_buffers():
+        n = n.replace("__", ".")
+        sd[n] = b.detach().cpu().to(dtype) if b.dtype.is_floating_point else b.detach().cpu().clone()
+    return sd

@@ -1,0 +1,17 @@
+"""MI355X-native (gfx950) implementation of the EDRL training hot path.
+
+Drop-in surface:
+    MedFusion(classes, modalties, classifiers_dims, args).forward(X, y, epoch) -> (pred, loss, combine_features)
+    MK_MMD(source, target, kernel_mul=2.0, kernel_num=5) -> 0-d tensor
+    train_step / train  (the loop body of fusion_train.py:176-225)
+Compute lives in libedrl_hip.so (hand-written HIP, C-ABI in include/edrl_hip.h); importing this
+package never builds or falls back: a missing library raises on first use.
+"""
+from . import _lib, ops
+from .mmd import MK_MMD
+from .medfusion import MedFusion, EPRL, PoE, DILR, AttentionModel, off_diagonal
+from .encoders import ResNetTrunk, FundusEncoder, OCTSliceEncoder
+from .train import train_step, train, synthetic_batch
+
+__all__ = ["MedFusion", "EPRL", "PoE", "DILR", "AttentionModel", "off_diagonal", "MK_MMD", "ResNetTrunk",
+           "FundusEncoder", "OCTSliceEncoder", "train_step", "train", "synthetic_batch", "ops"]

@@ -1,0 +1,406 @@
+// BatchNorm (train mode) statistics / apply / backward, pooling and layout kernels, NHWC fp32.
+// HBM-bound wavefront-reduction kernels with 16 B/lane coalesced accesses.
+//
+// Covers SURVEY.md §8(a) rows E3 (BN2d / ReLU / residual / maxpool / avgpool inside the
+// build-owned encoders behind fusion_net.py:884-885) and H13 (DILR.bn1/bn2,
+// fusion_net.py:653-654,658,757-758: BatchNorm1d(2048, affine=False), momentum 0.1, eps 1e-5,
+// biased variance to normalise, unbiased variance into running_var).
+//
+// Reductions are two-level and ordered (per-chunk fp32 partials, fp64 combine): deterministic,
+// no atomics.
+#include "edrl_common.h"
+
+#define BN_ROWS_PER_CHUNK 1024
+
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dout * (out > 0 if out given).
+template <int MODE>
+__global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                      const float* __restrict__ out,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, long M, int C, long ld,
+                                                      float* __restrict__ part) {
+  __shared__ float sh[256 * 8];
+  const int C4 = C >> 2;
+  const int CG = C4 < 64 ? C4 : 64;  // float4 column groups per block (power of two)
+  const int RL = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, rl = tid / CG;
+  const int c = (blockIdx.y * 64 + cg) * 4;
+  const long row0 = (long)blockIdx.x * BN_ROWS_PER_CHUNK;
+  long row1 = row0 + BN_ROWS_PER_CHUNK;
+  if (row1 > M) row1 = M;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const f32x4*>(mean + c);
+      rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    }
+    for (long r = row0 + rl; r < row1 && rl < RL; r += RL) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+      if (MODE == 0) {
+        s0 += xv;
+        s1 += xv * xv;
+      } else {
+        f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
+        if (out) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+        s0 += g;
+        s1 += g * ((xv - mu) * rs);
+      }
+    }
+  }
+  float* my = sh + tid * 8;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { my[e] = s0[e]; my[4 + e] = s1[e]; }
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int q = 0; q < RL; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += sh[(q * CG + cg) * 8 + e];
+    float* p = part + (long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[c + e] = a[e]; p[C + c + e] = a[4 + e]; }
+  }
+}
+
+// Combine chunk partials in fp64. block = 64 channels x 4 chunk lanes.
+__device__ __forceinline__ void combine_partials(const float* part, int nchunks, int C, int c, int q,
+                                                 double* sh, double& s0, double& s1) {
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C)
+    for (int k = q; k < nchunks; k += 4) {
+      a0 += (double)part[(long)k * 2 * C + c];
+      a1 += (double)part[(long)k * 2 * C + C + c];
+    }
+  const int t = threadIdx.x;
+  sh[t] = a0; sh[256 + t] = a1;
+  __syncthreads();
+  const int cc = t & 63;
+  s0 = sh[cc] + sh[64 + cc] + sh[128 + cc] + sh[192 + cc];
+  s1 = sh[256 + cc] + sh[320 + cc] + sh[384 + cc] + sh[448 + cc];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nchunks, int C,
+                                                          long M, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum,
+                                                          float eps, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  __shared__ double sh[512];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  double s0, s1;
+  combine_partials(part, nchunks, C, c, q, sh, s0, s1);
+  if (q == 0 && c < C) {
+    const double mu = s0 / (double)M;
+    double var = s1 / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    const float muf = (float)mu;
+    mean_out[c] = muf;
+    rstd_out[c] = rs;
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float sc = gm * rs;
+    scale[c] = sc;
+    shift[c] = bt - muf * sc;
+    if (running_mean) {
+      const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int C,
+                                                              long M, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ coef) {
+  __shared__ double sh[512];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  double s0, s1;
+  combine_partials(part, nchunks, C, c, q, sh, s0, s1);
+  if (q == 0 && c < C) {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s0 : (float)s0;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s1 : (float)s1;
+    coef[c] = (float)(s0 / (double)M);
+    coef[C + c] = (float)(s1 / (double)M);
+  }
+}
+
+// out = act(x*scale + shift + residual)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ residual,
+                                                       float* __restrict__ out, long M, int C, long ld, int relu) {
+  const int C4 = C >> 2;
+  const long total = M * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+    const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c);
+    f32x4 v = xv * sc + sf;
+    if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * ld + c);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + r * ld + c) = v;
+  }
+}
+
+// g = dout * (out>0);  dx = gamma*rstd*(g - c1 - xhat*c2);  dres (+)= g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ coef, float* __restrict__ dx, float* __restrict__ dres, int dres_accum, long M,
+    int C, long ld) {
+  const int C4 = C >> 2;
+  const long total = M * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
+    if (out) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+    }
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + c);
+    const f32x4 c2 = *reinterpret_cast<const f32x4*>(coef + C + c);
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 xh = (xv - mu) * rs;
+    const f32x4 d = gm * rs * (g - c1 - xh * c2);
+    if (dres) {
+      f32x4 v = g;
+      if (dres_accum) v += *reinterpret_cast<const f32x4*>(dres + r * ld + c);
+      *reinterpret_cast<f32x4*>(dres + r * ld + c) = v;
+    }
+    *reinterpret_cast<f32x4*>(dx + r * ld + c) = d;
+  }
+}
+
+// ------------------------------------------------------------------ pooling / layout
+// 3x3 stride-2 pad-1 max pool on NHWC; idx = kh*3+kw of the first maximum (scan order kh, kw).
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               unsigned char* __restrict__ idx, int N, int H,
+                                                               int W, int C, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float best = -INFINITY;
+    int bi = 0;
+    bool any = false;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = ho * 2 - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = wo * 2 - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        const float v = x[(((long)n * H + h) * W + w) * C + c];
+        if (!any || v > best || v != v) { best = v; bi = kh * 3 + kw; any = true; }
+      }
+    }
+    y[i] = best;
+    idx[i] = (unsigned char)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy,
+                                                               const unsigned char* __restrict__ idx,
+                                                               float* __restrict__ dx, int N, int H, int W, int C,
+                                                               int Ho, int Wo) {
+  const long total = (long)N * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float s = 0.f;
+    // windows (ho,wo) with ho*2-1+kh == h, kh in 0..2
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int th = h + 1 - kh;
+      if (th < 0 || (th & 1)) continue;
+      const int ho = th >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tw = w + 1 - kw;
+        if (tw < 0 || (tw & 1)) continue;
+        const int wo = tw >> 1;
+        if (wo >= Wo) continue;
+        const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
+        if (idx[o] == kh * 3 + kw) s += dy[o];
+      }
+    }
+    dx[i] = s;
+  }
+}
+
+// [N][C][H][W] -> [N][H][W][Cp] (channels >= C zero filled)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int N, int C, int H, int W, int Cp) {
+  const long total = (long)N * H * W * Cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    long t = i / Cp;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    out[i] = c < C ? in[(((long)n * C + c) * H + h) * W + w] : 0.f;
+  }
+}
+
+// in [A][L][D] -> out [A][D] = scale * sum_l in
+__global__ __launch_bounds__(256) void sum_axis1_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        long A, int L, int D, float scale) {
+  const long total = A * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long a = i / D;
+    const int d = (int)(i - a * D);
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += in[(a * L + l) * D + d];
+    out[i] = s * scale;
+  }
+}
+// out [A][L][D] (+)= scale * in [A][D]
+__global__ __launch_bounds__(256) void bcast_axis1_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          long A, int L, int D, float scale, int accumulate) {
+  const long total = A * L * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const long a = i / ((long)L * D);
+    const float v = in[a * D + d] * scale;
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+static inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" {
+
+size_t edrl_bn_workspace_bytes(long M, int C) {
+  const long chunks = (M + BN_ROWS_PER_CHUNK - 1) / BN_ROWS_PER_CHUNK;
+  return (size_t)chunks * 2 * C * sizeof(float);
+}
+
+// Train-mode batch statistics of x [M][C] (row stride ld) and the affine that applies them.
+int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            float* save_mean, float* save_rstd, float* scale, float* shift, float* workspace,
+                            size_t workspace_bytes, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C) return EDRL_EINVAL;
+  if (workspace_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
+  const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL(colstat_kernel<0>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, nullptr, nullptr,
+                     nullptr, nullptr, M, C, ld, workspace);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, 64)), dim3(256), 0, st, workspace, chunks, C, M, gamma,
+                     beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+int edrl_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
+                      long M, int C, long ld, int relu, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3) || (ld & 3)) return EDRL_EINVAL;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, scale, shift, residual, out,
+                     M, C, ld, relu);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// BN(+ReLU)(+residual) backward.  dout: grad of the post-activation output; out: that output (NULL = no ReLU).
+// dx: grad of the raw (pre-BN) tensor; dres (optional): grad of the residual operand, (+)= dout*mask.
+int edrl_bn_bwd_f32(const float* dout, const float* out, const float* x, const float* save_mean,
+                    const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, int accumulate,
+                    float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
+                    size_t workspace_bytes, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3) || (ld & 3)) return EDRL_EINVAL;
+  const size_t stats = edrl_bn_workspace_bytes(M, C);
+  if (workspace_bytes < stats + (size_t)2 * C * sizeof(float)) return EDRL_ENOSPC;
+  float* coef = workspace + stats / sizeof(float);
+  const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL(colstat_kernel<1>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout, out, save_mean,
+                     save_rstd, M, C, ld, workspace);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, 64)), dim3(256), 0, st, workspace, chunks, C, M,
+                     dgamma, dbeta, accumulate, coef);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, out, x, save_mean,
+                     save_rstd, gamma, coef, dx, dres, dres_accum, M, C, ld);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+int edrl_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C,
+                              hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return EDRL_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, idx, N,
+                     H, W, C, Ho, Wo);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,
+                              hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return EDRL_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, st, dy, idx, dx, N,
+                     H, W, C, Ho, Wo);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+int edrl_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C) return EDRL_EINVAL;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((long)N * H * W * Cp)), dim3(256), 0, st, in, out, N, C, H,
+                     W, Cp);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[a][d] = scale * sum_l in[a][l][d]   (global avg-pool, token mean)
+int edrl_sum_axis1_f32(const float* in, float* out, long A, int L, int D, float scale, hipStream_t st) {
+  if (A <= 0 || L <= 0 || D <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(sum_axis1_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, in, out, A, L, D, scale);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+// out[a][l][d] (+)= scale * in[a][d]
+int edrl_bcast_axis1_f32(const float* in, float* out, long A, int L, int D, float scale, int accumulate,
+                         hipStream_t st) {
+  if (A <= 0 || L <= 0 || D <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(bcast_axis1_kernel, dim3(ew_grid(A * L * D)), dim3(256), 0, st, in, out, A, L, D, scale,
+                     accumulate);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,568 @@
+// Implicit-GEMM convolution / linear kernels on the gfx950 fp32 matrix cores.
+//
+// Three contractions cover every conv and Linear on the EDRL hot path
+// (reference call sites
+// fusion_net.py:82-90,635-643,716-717,801-805 and the absent encoders :884-885):
+//
+//   gather  (fwd / dgrad):  D[m][n] = sum_k  Agather[m][k] * Wm[n][k]
+//       m = destination pixel (NHWC row), k = (kh,kw,c_src), n = destination channel.
+//       fwd  : src pixel = dst*stride - pad + tap
+//       dgrad: src pixel = (dst + pad - tap)/stride when divisible
+//       A Linear is the 1x1 case (OH=OW=1, rows = tokens).
+//   wgrad  (TN):            dW[co][k] = sum_pix dY[pix][co] * Xcol[pix][k]   (split-K over pixels)
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain; 64 FLOP/clk/SIMD).
+// Block = 256 threads = 2x2 waves; wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles.
+// K-contiguous operands are staged to LDS as [row][BK+4] and read with
+// ds_read_b128 (conflict-free at stride 36 dwords): one read feeds 4 MFMA
+// k-steps, lane half h taking k = 8*kc + 4*h + j.  Row-contiguous operands
+// (wgrad) are staged as [k][row] and read with ds_read_b32.
+// Global->LDS is register staged and double buffered (one barrier per K tile):
+// tile t+1's loads are issued before tile t's MFMAs and written after them.
+#include "edrl_common.h"
+
+#define BK 32
+#define LDK (BK + 4)
+
+struct GatherGeom {
+  int M;            // destination rows = N*OH*OW
+  int OH, OW;       // destination spatial
+  int NC;           // destination channels (GEMM N)
+  int SH, SW, SC;   // source spatial / channels
+  int KH, KW, stride, pad;
+  int Ktot;         // KH*KW*SC
+  long ld_src;      // source pixel stride (elements)
+  long ld_dst;      // destination pixel stride (elements)
+  long ld_aux;      // pixel stride of `mul` / `addend` operands (elements)
+  int flags;        // bit0 relu, bit1 accumulate into dst
+};
+
+#define GF_RELU 1
+#define GF_ACCUM 2
+
+template <int BM, int BN, bool DGRAD, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
+    const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
+    const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_LD = (BM * BK / 4) / 256;  // float4 loads per thread
+  constexpr int B_LD = (BN * BK / 4) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                   // [2][BM][LDK]
+  float* Bs = smem + 2 * BM * LDK;    // [2][BN][LDK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+  const int nwg = gridDim.x;
+  const int lid = edrl_xcd_remap(blockIdx.x, nwg);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-thread fixed staging coordinates
+  const int k4 = (tid & 7) * 4;
+  const int r0 = tid >> 3;  // rows r0 + 32*i
+  int rbase[A_LD];          // image index * SH*SW  (pixel units), -1 if row invalid
+  int rh[A_LD], rw[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const long m = m0 + r0 + 32 * i;
+    if (m < g.M) {
+      const int ohw = g.OH * g.OW;
+      const int n = (int)(m / ohw);
+      const int rem = (int)(m - (long)n * ohw);
+      const int oh = rem / g.OW, ow = rem - oh * g.OW;
+      rbase[i] = n;
+      if (DGRAD) { rh[i] = oh + g.pad; rw[i] = ow + g.pad; }
+      else       { rh[i] = oh * g.stride - g.pad; rw[i] = ow * g.stride - g.pad; }
+    } else { rbase[i] = -1; rh[i] = 0; rw[i] = 0; }
+  }
+
+  f32x4 a_st[A_LD], b_st[B_LD];
+
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + k4;
+    if (VEC) {
+      const bool kvalid = k < g.Ktot;
+      int tap = 0, c = 0, kh = 0, kw = 0;
+      if (kvalid) { tap = k / g.SC; c = k - tap * g.SC; kh = tap / g.KW; kw = tap - kh * g.KW; }
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        bool ok = kvalid && rbase[i] >= 0;
+        int sh, sw;
+        if (DGRAD) {
+          const int th = rh[i] - kh, tw = rw[i] - kw;
+          ok = ok && th >= 0 && tw >= 0 && (th % g.stride) == 0 && (tw % g.stride) == 0;
+          sh = th / g.stride; sw = tw / g.stride;
+        } else { sh = rh[i] + kh; sw = rw[i] + kw; }
+        ok = ok && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+        if (ok) {
+          const long pix = ((long)rbase[i] * g.SH + sh) * g.SW + sw;
+          v = *reinterpret_cast<const f32x4*>(src + pix * g.ld_src + c);
+        }
+        a_st[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kvalid && n < g.NC) v = *reinterpret_cast<const f32x4*>(wm + (long)n * g.Ktot + k);
+        b_st[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) a_st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ke = k + e;
+        const bool kvalid = ke < g.Ktot;
+        int tap = 0, c = 0, kh = 0, kw = 0;
+        if (kvalid) { tap = ke / g.SC; c = ke - tap * g.SC; kh = tap / g.KW; kw = tap - kh * g.KW; }
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          bool ok = kvalid && rbase[i] >= 0;
+          int sh, sw;
+          if (DGRAD) {
+            const int th = rh[i] - kh, tw = rw[i] - kw;
+            ok = ok && th >= 0 && tw >= 0 && (th % g.stride) == 0 && (tw % g.stride) == 0;
+            sh = th / g.stride; sw = tw / g.stride;
+          } else { sh = rh[i] + kh; sw = rw[i] + kw; }
+          ok = ok && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+          float v = 0.f;
+          if (ok) {
+            const long pix = ((long)rbase[i] * g.SH + sh) * g.SW + sw;
+            v = src[pix * g.ld_src + c];
+          }
+          a_st[i][e] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+          const int n = n0 + r0 + 32 * i;
+          float v = 0.f;
+          if (kvalid && n < g.NC) v = wm[(long)n * g.Ktot + ke];
+          b_st[i][e] = v;
+        }
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* a = As + buf * BM * LDK;
+    float* b = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDK + k4) = a_st[i];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDK + k4) = b_st[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = (g.Ktot + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const float* a = As + buf * BM * LDK + (wm0 + li) * LDK + 4 * lh;
+    const float* b = Bs + buf * BN * LDK + (wn0 + li) * LDK + 4 * lh;
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + kc * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + kc * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool relu = g.flags & GF_RELU, accum = g.flags & GF_ACCUM;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + li;
+    if (n >= g.NC) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < g.M) {
+          float v = acc[i][j][r] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (mul) v *= mul[m * g.ld_aux + n];
+          float* p = dst + m * g.ld_dst + n;
+          if (accum) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool DGRAD, bool VEC>
+static int launch_gather(const float* src, const float* wm, float* dst, const float* bias,
+                         const float* mul, const GatherGeom& g, hipStream_t st) {
+  const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
+  const long nblk = (long)tiles_m * tiles_n;
+  if (nblk <= 0) return 0;
+  if (nblk > 0x7fffffffL) return EDRL_EINVAL;
+  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  auto kern = conv_gather_f32_kernel<BM, BN, DGRAD, VEC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, g, tiles_n);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool DGRAD>
+static int dispatch_gather(const float* src, const float* wm, float* dst, const float* bias,
+                           const float* mul, const GatherGeom& g, hipStream_t st) {
+  const bool vec = (g.SC % 4 == 0) && (g.ld_src % 4 == 0) && (g.Ktot % 4 == 0) &&
+                   (((uintptr_t)src & 15) == 0) && (((uintptr_t)wm & 15) == 0);
+  const bool narrow = g.NC <= 64;
+  if (vec) {
+    if (narrow) return launch_gather<128, 64, DGRAD, true>(src, wm, dst, bias, mul, g, st);
+    return launch_gather<128, 128, DGRAD, true>(src, wm, dst, bias, mul, g, st);
+  }
+  if (narrow) return launch_gather<128, 64, DGRAD, false>(src, wm, dst, bias, mul, g, st);
+  return launch_gather<128, 128, DGRAD, false>(src, wm, dst, bias, mul, g, st);
+}
+
+// ------------------------------------------------------------------ wgrad (TN, split-K)
+struct WgradGeom {
+  long P;           // pixels = N*OH*OW (reduction length)
+  int OH, OW;
+  int Co;           // rows of dW
+  int SH, SW, SC;
+  int KH, KW, stride, pad;
+  int Ktot;         // KH*KW*SC columns of dW
+  long ld_dy, ld_x;
+  int tiles_per_split;
+};
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_LD = (BM * BK / 4) / 256, B_LD = (BN * BK / 4) / 256;
+  constexpr int AC4 = BM / 4, BC4 = BN / 4;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][BK][LDA]
+  float* Bs = smem + 2 * BK * LDA;     // [2][BK][LDB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int co0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int split = blockIdx.z;
+
+  const long ptiles = (g.P + BK - 1) / BK;
+  const long t_begin = (long)split * g.tiles_per_split;
+  long t_end = t_begin + g.tiles_per_split;
+  if (t_end > ptiles) t_end = ptiles;
+
+  // fixed column decode for the im2col operand
+  const int bc4 = tid % BC4;
+  const int kcol = n0 + bc4 * 4;
+  int ktap = 0, kc = 0, kkh = 0, kkw = 0;
+  const bool kvalid = kcol < g.Ktot;
+  if (VEC && kvalid) { ktap = kcol / g.SC; kc = kcol - ktap * g.SC; kkh = ktap / g.KW; kkw = ktap - kkh * g.KW; }
+  const int ac4 = tid % AC4;
+  const int ohw = g.OH * g.OW;
+
+  f32x4 a_st[A_LD], b_st[B_LD];
+  auto load_tile = [&](long t) {
+    const long p0 = t * BK;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int row = (tid + 256 * i) / AC4;
+      const long p = p0 + row;
+      const int co = co0 + ac4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < g.P && co < g.Co) v = *reinterpret_cast<const f32x4*>(dy + p * g.ld_dy + co);
+      a_st[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int row = (tid + 256 * i) / BC4;
+      const long p = p0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < g.P) {
+        const int n = (int)(p / ohw);
+        const int rem = (int)(p - (long)n * ohw);
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        if (VEC) {
+          if (kvalid) {
+            const int sh = oh * g.stride - g.pad + kkh, sw = ow * g.stride - g.pad + kkw;
+            if (sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW) {
+              const long pix = ((long)n * g.SH + sh) * g.SW + sw;
+              v = *reinterpret_cast<const f32x4*>(x + pix * g.ld_x + kc);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ke = kcol + e;
+            if (ke < g.Ktot) {
+              const int tap = ke / g.SC, c = ke - tap * g.SC;
+              const int kh = tap / g.KW, kw = tap - kh * g.KW;
+              const int sh = oh * g.stride - g.pad + kh, sw = ow * g.stride - g.pad + kw;
+              if (sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW) {
+                const long pix = ((long)n * g.SH + sh) * g.SW + sw;
+                v[e] = x[pix * g.ld_x + c];
+              }
+            }
+          }
+        }
+      }
+      b_st[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* a = As + buf * BK * LDA;
+    float* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int row = (tid + 256 * i) / AC4;
+      *reinterpret_cast<f32x4*>(a + row * LDA + ac4 * 4) = a_st[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int row = (tid + 256 * i) / BC4;
+      *reinterpret_cast<f32x4*>(b + row * LDB + bc4 * 4) = b_st[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  if (t_begin < t_end) {
+    load_tile(t_begin);
+    store_tile(0);
+    __syncthreads();
+    for (long t = t_begin; t < t_end; ++t) {
+      const int buf = (int)((t - t_begin) & 1);
+      if (t + 1 < t_end) load_tile(t + 1);
+      const float* a = As + buf * BK * LDA + wm0 + li;
+      const float* b = Bs + buf * BK * LDB + wn0 + li;
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        const int k = 2 * ks + lh;
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = a[k * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = b[k * LDB + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (t + 1 < t_end) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  float* out = part + (long)split * g.Co * g.Ktot;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + li;
+    if (n >= g.Ktot) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < g.Co) out[(long)co * g.Ktot + n] = acc[i][j][r];
+      }
+  }
+}
+
+// dW[i] = (accumulate ? dW[i] : 0) + sum_s part[s][i]   (fixed order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n,
+                                     int splits, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(long)z * n + i];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+template <int BM, int BN, bool VEC>
+static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
+                        hipStream_t st) {
+  const size_t lds = (size_t)2 * BK * ((BM + 4) + (BN + 4)) * sizeof(float);
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(edrl_cdiv(g.Ktot, BN), edrl_cdiv(g.Co, BM), splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dy, x, part, g);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+static void wgrad_plan(long P, int Co, int Ktot, int* bm, int* bn, int* splits, int* tiles_per_split) {
+  *bm = Co <= 64 ? 64 : 128;
+  *bn = Ktot <= 64 ? 64 : 128;
+  const long tiles = (long)edrl_cdiv(Co, *bm) * edrl_cdiv(Ktot, *bn);
+  const long ptiles = (P + BK - 1) / BK;
+  long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU in flight
+  long max_by_len = ptiles / 8; if (max_by_len < 1) max_by_len = 1;   // >= 8 K tiles per split
+  long s = want < max_by_len ? want : max_by_len;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  long tps = (ptiles + s - 1) / s;
+  s = (ptiles + tps - 1) / tps;
+  if (s < 1) s = 1;
+  *splits = (int)s;
+  *tiles_per_split = (int)tps;
+}
+
+// [R][C] -> [C][R] per batch slice (weights [Co][taps][Ci] -> [Ci][taps][Co] uses R=Co, inner handled by caller)
+__global__ void permute_021_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int B, int C) {
+  // in [A][B][C] -> out [C][B][A]
+  const long n = (long)A * B * C;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = (int)(i % A);
+  const long t = i / A;
+  const int b = (int)(t % B);
+  const int c = (int)(t / B);
+  out[i] = in[((long)a * B + b) * C + c];
+}
+
+extern "C" {
+
+// Convolution forward on NHWC fp32 (also any Linear: KH=KW=1, H=W=1, N=rows).
+// y[n,ho,wo,co] = act( sum x[n,ho*s-p+kh,wo*s-p+kw,ci] * w[co,kh,kw,ci] + bias[co] ) * mul + (accum ? y : 0)
+int edrl_conv2d_nhwc_fwd_f32(const float* x, const float* w, const float* bias, const float* mul,
+                             float* y, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                             int KW, int stride, int pad, long ld_x, long ld_y, long ld_aux, int flags,
+                             hipStream_t st) {
+  if (N < 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || KH <= 0 || KW <= 0 ||
+      stride <= 0 || pad < 0 || ld_x < Ci || ld_y < Co)
+    return EDRL_EINVAL;
+  if ((long)(Ho - 1) * stride - pad + KH - 1 > (long)Hi - 1 + pad) return EDRL_EINVAL;
+  GatherGeom g;
+  g.M = (int)((long)N * Ho * Wo);
+  if ((long)N * Ho * Wo > 0x7fffffffL) return EDRL_EINVAL;
+  g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_src = ld_x; g.ld_dst = ld_y; g.ld_aux = ld_aux; g.flags = flags;
+  return dispatch_gather<false>(x, w, y, bias, mul, g, st);
+}
+
+// Convolution data gradient: dx[n,hi,wi,ci] (+)= sum dy[n,ho,wo,co] * wt[ci,kh,kw,co]
+// `wt` is the [Ci][KH][KW][Co] permutation of the forward weight (edrl_permute_weight_f32).
+int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int Hi, int Wi, int Ci,
+                               int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, long ld_dy,
+                               long ld_dx, int flags, hipStream_t st) {
+  if (N < 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 ||
+      ld_dy < Co || ld_dx < Ci)
+    return EDRL_EINVAL;
+  if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
+  GatherGeom g;
+  g.M = (int)((long)N * Hi * Wi);
+  g.OH = Hi; g.OW = Wi; g.NC = Ci; g.SH = Ho; g.SW = Wo; g.SC = Co;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Co;
+  g.ld_src = ld_dy; g.ld_dst = ld_dx; g.ld_aux = 0; g.flags = flags;
+  return dispatch_gather<true>(dy, wt, dx, nullptr, nullptr, g, st);
+}
+
+size_t edrl_conv2d_nhwc_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW) {
+  int bm, bn, splits, tps;
+  wgrad_plan((long)N * Ho * Wo, Co, KH * KW * Ci, &bm, &bn, &splits, &tps);
+  return (size_t)splits * Co * KH * KW * Ci * sizeof(float);
+}
+
+// Convolution weight gradient: dw[co,kh,kw,ci] (+)= sum_pix dy[pix,co] * x[pix @ tap, ci]
+int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace,
+                               size_t workspace_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
+                               int Co, int KH, int KW, int stride, int pad, long ld_dy, long ld_x,
+                               int accumulate, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 ||
+      ld_dy < Co || ld_x < Ci)
+    return EDRL_EINVAL;
+  WgradGeom g;
+  g.P = (long)N * Ho * Wo;
+  g.OH = Ho; g.OW = Wo; g.Co = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_dy = ld_dy; g.ld_x = ld_x;
+  int bm, bn, splits;
+  wgrad_plan(g.P, Co, g.Ktot, &bm, &bn, &splits, &g.tiles_per_split);
+  const size_t need = (size_t)splits * Co * g.Ktot * sizeof(float);
+  if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
+  const bool vec = (Ci % 4 == 0) && (ld_x % 4 == 0) && (Co % 4 == 0) && (ld_dy % 4 == 0) &&
+                   (((uintptr_t)dy & 15) == 0) && (((uintptr_t)x & 15) == 0);
+  // the dY operand is always read as float4: require it
+  if ((Co % 4) || (ld_dy % 4) || ((uintptr_t)dy & 15)) return EDRL_EINVAL;
+  int rc;
+  if (bm == 64 && bn == 64)
+    rc = vec ? launch_wgrad<64, 64, true>(dy, x, workspace, g, splits, st)
+             : launch_wgrad<64, 64, false>(dy, x, workspace, g, splits, st);
+  else if (bm == 64)
+    rc = vec ? launch_wgrad<64, 128, true>(dy, x, workspace, g, splits, st)
+             : launch_wgrad<64, 128, false>(dy, x, workspace, g, splits, st);
+  else if (bn == 64)
+    rc = vec ? launch_wgrad<128, 64, true>(dy, x, workspace, g, splits, st)
+             : launch_wgrad<128, 64, false>(dy, x, workspace, g, splits, st);
+  else
+    rc = vec ? launch_wgrad<128, 128, true>(dy, x, workspace, g, splits, st)
+             : launch_wgrad<128, 128, false>(dy, x, workspace, g, splits, st);
+  if (rc) return rc;
+  const long n = (long)Co * g.Ktot;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(edrl_cdiv(n, 256)), dim3(256), 0, st, workspace, dw, n,
+                     splits, accumulate);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// in [A][B][C] -> out [C][B][A]   (weight [Co][taps][Ci] -> [Ci][taps][Co]; B=1 gives a matrix transpose)
+int edrl_permute_weight_f32(const float* in, float* out, int A, int B, int C, hipStream_t st) {
+  if (A <= 0 || B <= 0 || C <= 0) return EDRL_EINVAL;
+  const long n = (long)A * B * C;
+  hipLaunchKernelGGL(permute_021_kernel, dim3(edrl_cdiv(n, 256)), dim3(256), 0, st, in, out, A, B, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

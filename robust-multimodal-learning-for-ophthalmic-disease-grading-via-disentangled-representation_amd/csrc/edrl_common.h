@@ -1,0 +1,67 @@
+// Shared device helpers for the EDRL gfx950 (CDNA4) kernels.
+// gfx950 only: 64-wide wavefronts, MFMA matrix cores, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define EDRL_WAVE 64
+
+// Error convention of the C-ABI: 0 = ok, otherwise a hipError_t value, or a
+// negative EDRL_E* code for argument violations detected on the host.
+#define EDRL_EINVAL (-22)
+#define EDRL_ENOSPC (-28)
+
+#define EDRL_LAUNCH_CHECK()                      \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)
+
+static inline int edrl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware bijective block remap (8 XCDs, blocks are dealt round-robin):
+// blocks that share an XCD get a contiguous range of logical tile ids so
+// that tiles sharing operand panels hit the same 4 MiB L2.
+__device__ __forceinline__ int edrl_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+__device__ __forceinline__ float edrl_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double edrl_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float edrl_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves). `sh` must hold >= 4 floats.
+__device__ __forceinline__ float edrl_block_sum_256(float v, float* sh) {
+  v = edrl_wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ double edrl_block_sum_256_d(double v, double* sh) {
+  v = edrl_wave_sum_d(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}

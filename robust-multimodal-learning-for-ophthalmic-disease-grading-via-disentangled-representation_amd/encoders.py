@@ -1,0 +1,302 @@
+"""Build-owned CNN image encoders for the two EDRL encoder slots.
+
+The reference's encoders (`Models.fundus_swin_network.build_model`, `Models.unetr.UNETR_base_3DNet`,
+fusion_net.py:1-2,796,799) are absent from the reference repository; it only fixes the contract
+    transformer_2DNet(X[0]) -> (tokens [B, N2, 1024], pooled)
+    transformer_3DNet(X[1]) -> (tokens [B, N3,  768], pooled)          (fusion_net.py:884-885)
+BASELINE.json names ResNet-18 / ResNet-50: fundus 2D, OCT as a slice stack (B*S single-channel
+images through a 2D ResNet, one token per slice).  Topology: He et al. v1.5 (7x7/2 stem, 3x3/2
+max-pool, [2,2,2,2] basic or [3,4,6,3] bottleneck blocks with the stride on the 3x3).
+
+MI355X layout: activations NHWC fp32, conv weights [Co,KH,KW,Ci]; the whole trunk is ONE
+autograd node whose forward/backward sequence the HIP launchers directly (implicit-GEMM MFMA
+convs, two-level BN reductions, fused BN+ReLU(+residual) apply) — no per-layer autograd graph.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+P = L.ptr
+
+_CFG = {
+    18: ("basic", [2, 2, 2, 2], 1),
+    34: ("basic", [3, 4, 6, 3], 1),
+    50: ("bottleneck", [3, 4, 6, 3], 4),
+}
+
+
+def _bn_ws(M, C, device, extra=0):
+    nbytes = L.query("edrl_bn_workspace_bytes", M, C) + extra
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32), nbytes
+
+
+def _bn_fwd(raw, bn, relu, residual=None):
+    """raw [N,H,W,C] -> (out, mean, rstd). Train-mode statistics; running stats updated in place."""
+    C = raw.shape[-1]
+    M = raw.numel() // C
+    dev = raw.device
+    mean = torch.empty(C, device=dev, dtype=torch.float32)
+    rstd = torch.empty_like(mean); scale = torch.empty_like(mean); shift = torch.empty_like(mean)
+    ws, nbytes = _bn_ws(M, C, dev)
+    L.call("edrl_bn_train_stats_f32", P(raw), M, C, C, P(bn["weight"]), P(bn["bias"]), P(bn["running_mean"]),
+           P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(mean), P(rstd), P(scale), P(shift),
+           P(ws), nbytes)
+    out = torch.empty_like(raw)
+    L.call("edrl_bn_apply_f32", P(raw), P(scale), P(shift), P(residual), P(out), M, C, C, 1 if relu else 0)
+    return out, mean, rstd
+
+
+def _bn_bwd(dout, out, raw, mean, rstd, gamma, want_dres):
+    """-> (d_raw, dgamma, dbeta, dres). `out` None means no ReLU on this BN's output."""
+    C = raw.shape[-1]
+    M = raw.numel() // C
+    dev = raw.device
+    d_raw = torch.empty_like(raw)
+    dgamma = torch.empty(C, device=dev, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    dres = torch.empty_like(raw) if want_dres else None
+    ws, nbytes = _bn_ws(M, C, dev, extra=2 * C * 4)
+    L.call("edrl_bn_bwd_f32", P(dout), P(out), P(raw), P(mean), P(rstd), P(gamma), P(dgamma), P(dbeta), 0,
+           P(d_raw), P(dres), 0, M, C, C, P(ws), nbytes)
+    return d_raw, dgamma, dbeta, dres
+
+
+class _TrunkFn(torch.autograd.Function):
+    """x NHWC [N,H,W,Cin] -> feature map NHWC [N,h,w,C].  params: flat tensor list (see ResNetTrunk)."""
+
+    @staticmethod
+    def forward(ctx, trunk, x, *params):
+        T = trunk
+        p = dict(zip(T.param_names, params))
+        bnd = T.bn_dict
+        saved = {}
+        x = ops._chk(x, "encoder input")
+
+        def conv(name, inp, stride, pad):
+            return ops.conv2d_fwd(inp, p[name + ".weight"], stride=stride, pad=pad)
+
+        raw = conv("conv1", x, 2, 3)
+        a0, m0, r0 = _bn_fwd(raw, bnd("bn1", p), True)
+        N, H, W, C = a0.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        p0 = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        L.call("edrl_maxpool3x3s2_fwd_f32", P(a0), P(p0), P(idx), N, H, W, C)
+        saved["stem"] = (x, raw, a0, m0, r0, idx)
+        cur = p0
+        for blk in T.blocks:
+            pre, s = blk["name"], blk["stride"]
+            rec = {"x": cur}
+            if T.kind == "bottleneck":
+                c1 = conv(pre + ".conv1", cur, 1, 0)
+                a1, m1, r1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
+                c2 = conv(pre + ".conv2", a1, s, 1)
+                a2, m2, r2 = _bn_fwd(c2, bnd(pre + ".bn2", p), True)
+                c3 = conv(pre + ".conv3", a2, 1, 0)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), c2=c2, a2=a2, s2=(m2, r2), c3=c3)
+                last, last_bn = c3, pre + ".bn3"
+            else:
+                c1 = conv(pre + ".conv1", cur, s, 1)
+                a1, m1, r1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
+                c2 = conv(pre + ".conv2", a1, 1, 1)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), c2=c2)
+                last, last_bn = c2, pre + ".bn2"
+            if blk["downsample"]:
+                cd = conv(pre + ".downsample.0", cur, s, 0)
+                idn, md, rd = _bn_fwd(cd, bnd(pre + ".downsample.1", p), False)
+                rec.update(cd=cd, sd=(md, rd))
+            else:
+                idn = cur
+            out, ml, rl = _bn_fwd(last, bnd(last_bn, p), True, residual=idn)
+            rec.update(out=out, sl=(ml, rl))
+            saved[pre] = rec
+            cur = out
+        ctx.trunk = T
+        ctx.saved = saved
+        ctx.params = p
+        ctx.needs_x = x.requires_grad
+        T.bump_batches_tracked()
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, saved, p = ctx.trunk, ctx.saved, ctx.params
+        ctx.saved = None
+        grads = {}
+        dcur = dout.contiguous()
+
+        def conv_bwd(name, dy, inp, stride, pad, need_dx=True, dx_out=None, accumulate=False):
+            w = p[name + ".weight"]
+            grads[name + ".weight"] = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+            if not need_dx:
+                return None
+            return ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
+                                    accumulate=accumulate)
+
+        def bn_bwd(name, dy, out, raw, st, want_dres=False):
+            d_raw, dg, db, dres = _bn_bwd(dy, out, raw, st[0], st[1], p[name + ".weight"], want_dres)
+            grads[name + ".weight"] = dg
+            grads[name + ".bias"] = db
+            return d_raw, dres
+
+        for blk in reversed(T.blocks):
+            pre, s = blk["name"], blk["stride"]
+            rec = saved.pop(pre)
+            xin = rec["x"]
+            if T.kind == "bottleneck":
+                d3, g = bn_bwd(pre + ".bn3", dcur, rec["out"], rec["c3"], rec["sl"], want_dres=True)
+            else:
+                d3, g = bn_bwd(pre + ".bn2", dcur, rec["out"], rec["c2"], rec["sl"], want_dres=True)
+            # identity / downsample branch -> dx
+            if blk["downsample"]:
+                dd, _ = bn_bwd(pre + ".downsample.1", g, None, rec["cd"], rec["sd"])
+                dx = conv_bwd(pre + ".downsample.0", dd, xin, s, 0)
+                del dd
+            else:
+                dx = g
+            del g
+            if T.kind == "bottleneck":
+                da2 = conv_bwd(pre + ".conv3", d3, rec["a2"], 1, 0)
+                d2, _ = bn_bwd(pre + ".bn2", da2, rec["a2"], rec["c2"], rec["s2"])
+                da1 = conv_bwd(pre + ".conv2", d2, rec["a1"], s, 1)
+                d1, _ = bn_bwd(pre + ".bn1", da1, rec["a1"], rec["c1"], rec["s1"])
+                conv_bwd(pre + ".conv1", d1, xin, 1, 0, dx_out=dx, accumulate=True)
+            else:
+                da1 = conv_bwd(pre + ".conv2", d3, rec["a1"], 1, 1)
+                d1, _ = bn_bwd(pre + ".bn1", da1, rec["a1"], rec["c1"], rec["s1"])
+                conv_bwd(pre + ".conv1", d1, xin, s, 1, dx_out=dx, accumulate=True)
+            dcur = dx
+            del rec
+        x, raw, a0, m0, r0, idx = saved.pop("stem")
+        N, H, W, C = a0.shape
+        da0 = torch.empty_like(a0)
+        L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
+        draw, _ = bn_bwd("bn1", da0, a0, raw, (m0, r0))
+        dx = conv_bwd("conv1", draw, x, 2, 3, need_dx=ctx.needs_x)
+        return (None, dx) + tuple(grads.get(n) for n in T.param_names)
+
+
+class ResNetTrunk(nn.Module):
+    """ResNet-18/34/50 trunk (no fc), NHWC fp32, HIP kernels only."""
+
+    def __init__(self, depth=50, in_ch=3):
+        super().__init__()
+        kind, layers, expansion = _CFG[depth]
+        self.kind, self.depth, self.in_ch = kind, depth, in_ch
+        self.in_ch_padded = in_ch if in_ch == 1 else (in_ch + 3) // 4 * 4
+        self.blocks = []
+        self._bn_names = []
+        self._add_conv("conv1", 64, 7, self.in_ch_padded, real_ci=in_ch)
+        self._add_bn("bn1", 64)
+        inpl = 64
+        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], layers)):
+            for bi in range(nblk):
+                stride = 2 if (bi == 0 and li > 0) else 1
+                pre = f"layer{li + 1}.{bi}"
+                outp = planes * expansion
+                ds = (stride != 1) or (inpl != outp)
+                if kind == "bottleneck":
+                    self._add_conv(pre + ".conv1", planes, 1, inpl); self._add_bn(pre + ".bn1", planes)
+                    self._add_conv(pre + ".conv2", planes, 3, planes); self._add_bn(pre + ".bn2", planes)
+                    self._add_conv(pre + ".conv3", outp, 1, planes); self._add_bn(pre + ".bn3", outp, zero=False)
+                else:
+                    self._add_conv(pre + ".conv1", planes, 3, inpl); self._add_bn(pre + ".bn1", planes)
+                    self._add_conv(pre + ".conv2", planes, 3, planes); self._add_bn(pre + ".bn2", planes)
+                if ds:
+                    self._add_conv(pre + ".downsample.0", outp, 1, inpl); self._add_bn(pre + ".downsample.1", outp)
+                self.blocks.append({"name": pre, "stride": stride, "downsample": ds})
+                inpl = outp
+        self.out_channels = inpl
+        self.param_names = [n for n, _ in self.named_parameters()]
+
+    # parameters are registered under dotted torchvision-style names with '.' -> '__' for attribute safety
+    def _reg(self, name, tensor, buffer=False):
+        key = name.replace(".", "__")
+        if buffer:
+            self.register_buffer(key, tensor)
+        else:
+            self.register_parameter(key, nn.Parameter(tensor))
+
+    def _add_conv(self, name, co, k, ci, real_ci=None):
+        w = torch.empty(co, k, k, ci)
+        fan_out = co * k * k  # kaiming_normal_(mode='fan_out', nonlinearity='relu')
+        w.normal_(0.0, math.sqrt(2.0 / fan_out))
+        if real_ci is not None and real_ci < ci:
+            w[..., real_ci:] = 0.0
+        self._reg(name + ".weight", w)
+
+    def _add_bn(self, name, c, zero=False):
+        self._reg(name + ".weight", torch.zeros(c) if zero else torch.ones(c))
+        self._reg(name + ".bias", torch.zeros(c))
+        self._reg(name + ".running_mean", torch.zeros(c), buffer=True)
+        self._reg(name + ".running_var", torch.ones(c), buffer=True)
+        self._reg(name + ".num_batches_tracked", torch.zeros((), dtype=torch.long), buffer=True)
+        self._bn_names.append(name)
+
+    def named_parameters(self, *a, **k):
+        for n, v in super().named_parameters(*a, **k):
+            yield n.replace("__", "."), v
+
+    def get(self, name):
+        return getattr(self, name.replace(".", "__"))
+
+    def bn_dict(self, name, p):
+        return {"weight": p[name + ".weight"], "bias": p[name + ".bias"],
+                "running_mean": self.get(name + ".running_mean"), "running_var": self.get(name + ".running_var"),
+                "momentum": 0.1, "eps": 1e-5}
+
+    def bump_batches_tracked(self):
+        torch._foreach_add_([self.get(n + ".num_batches_tracked") for n in self._bn_names], 1)
+
+    def forward(self, x_nhwc):
+        if not self.training:
+            raise NotImplementedError("eval-mode (running-stat) encoder forward is a SURVEY §8(f) 'next' row")
+        params = [self.get(n) for n in self.param_names]
+        return _TrunkFn.apply(self, x_nhwc, *params)
+
+
+class FundusEncoder(nn.Module):
+    """2D fundus encoder slot: [B,3,H,W] (NCHW, as the loader emits, data_harvard.py:830-841)
+    -> (tokens [B, (H/32)*(W/32), token_dim], pooled [B, token_dim])."""
+
+    def __init__(self, depth=50, token_dim=1024):
+        super().__init__()
+        self.trunk = ResNetTrunk(depth, in_ch=3)
+        c = self.trunk.out_channels
+        self.token_proj = nn.Linear(c, token_dim)
+
+    def forward(self, x):
+        ops._chk(x, "fundus")
+        B, C, H, W = x.shape
+        cp = self.trunk.in_ch_padded
+        xh = torch.empty((B, H, W, cp), device=x.device, dtype=torch.float32)
+        L.call("edrl_nchw_to_nhwc_f32", P(x), P(xh), B, C, H, W, cp)
+        f = self.trunk(xh)                                  # [B,h,w,C]
+        tok = f.view(B, f.shape[1] * f.shape[2], f.shape[3])
+        tokens = ops.linear(tok, self.token_proj.weight, self.token_proj.bias)
+        return tokens, ops.mean_axis1(tokens)
+
+
+class OCTSliceEncoder(nn.Module):
+    """OCT slice-stack encoder slot: [B,1,S,H,W] -> (tokens [B, S, token_dim], pooled [B, token_dim]).
+    The S slices run through the 2D trunk as a batch of B*S single-channel images."""
+
+    def __init__(self, depth=50, token_dim=768):
+        super().__init__()
+        self.trunk = ResNetTrunk(depth, in_ch=1)
+        c = self.trunk.out_channels
+        self.token_proj = nn.Linear(c, token_dim)
+
+    def forward(self, x):
+        ops._chk(x, "oct")
+        B, C, S, H, W = x.shape
+        assert C == 1
+        xh = x.view(B * S, H, W, 1)                         # single channel: NCHW == NHWC
+        f = self.trunk(xh)                                  # [B*S,h,w,C]
+        pooled = ops.mean_axis1(f.view(B * S, f.shape[1] * f.shape[2], f.shape[3]))   # global avg pool
+        tokens = ops.linear(pooled.view(B, S, -1), self.token_proj.weight, self.token_proj.bias)
+        return tokens, ops.mean_axis1(tokens)

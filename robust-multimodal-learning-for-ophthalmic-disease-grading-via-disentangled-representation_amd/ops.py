@@ -1,0 +1,670 @@
+"""Operator layer: torch.autograd.Function wrappers over the C-ABI HIP launchers.
+
+Every forward and backward below runs hand-written gfx950 kernels from libedrl_hip.so on torch's
+current stream.  torch is used only for device memory (torch.empty from the caching allocator),
+views/concatenation and autograd bookkeeping.  There is no eager/CPU fallback: tensors that are
+not fp32 CUDA tensors are rejected.
+"""
+import torch
+
+from . import _lib as L
+
+P = L.ptr
+
+EW_RELU, EW_RELU_BWD, EW_AXPBY, EW_MUL, EW_SCALE, EW_SOFTPLUS, EW_SOFTPLUS_BWD, EW_MASKED_BWD, \
+    EW_ADD_RELU, EW_SCALE_BY_PTR, EW_FILL = range(11)
+FLAG_RELU, FLAG_ACCUM = 1, 2
+
+
+def _chk(t, name="tensor", contiguous=True):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f"{name}: expected a float32 CUDA tensor (the EDRL hot path is HIP-only), "
+                           f"got {type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    if contiguous and not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor, got strides {t.stride()}")
+    return t
+
+
+def _rows2d(x):
+    """View x [..., D] as [rows, D] with unit inner stride (row stride may exceed D)."""
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+        x2 = x2.contiguous()
+    return x2
+
+
+def _ld(x2):
+    return x2.stride(0) if x2.shape[0] > 1 else max(x2.stride(0), x2.shape[1])
+
+
+# ------------------------------------------------------------------ raw (non-autograd) launch helpers
+def ew(op, a, b=None, c=None, out=None, alpha=1.0, beta=1.0):
+    a = a.contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    L.call("edrl_ew_f32", op, a.numel(), P(a), P(b), P(c), P(out), float(alpha), float(beta))
+    return out
+
+
+def conv2d_fwd(x, w, bias=None, mul=None, stride=1, pad=0, relu=False, out=None, accumulate=False):
+    """x [N,Hi,Wi,Ci] NHWC, w [Co,KH,KW,Ci] -> y [N,Ho,Wo,Co]."""
+    N, Hi, Wi, Ci = x.shape
+    Co, KH, KW, _ = w.shape
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.float32)
+    flags = (FLAG_RELU if relu else 0) | (FLAG_ACCUM if accumulate else 0)
+    L.call("edrl_conv2d_nhwc_fwd_f32", P(x), P(w), P(bias), P(mul), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW,
+           stride, pad, Ci, Co, Co, flags)
+    return out
+
+
+def permute_weight(w):
+    """[Co,KH,KW,Ci] -> [Ci,KH,KW,Co] (or [out,in] -> [in,out])."""
+    if w.dim() == 2:
+        A, B, C = w.shape[0], 1, w.shape[1]
+        out = torch.empty((C, A), device=w.device, dtype=torch.float32)
+    else:
+        A, B, C = w.shape[0], w.shape[1] * w.shape[2], w.shape[3]
+        out = torch.empty((C, w.shape[1], w.shape[2], A), device=w.device, dtype=torch.float32)
+    L.call("edrl_permute_weight_f32", P(w), P(out), A, B, C)
+    return out
+
+
+def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=False):
+    """dy [N,Ho,Wo,Co], wt [Ci,KH,KW,Co] -> dx [N,Hi,Wi,Ci]."""
+    N, Hi, Wi, Ci = x_shape
+    _, Ho, Wo, Co = dy.shape
+    KH, KW = wt.shape[1], wt.shape[2]
+    if out is None:
+        out = torch.empty((N, Hi, Wi, Ci), device=dy.device, dtype=torch.float32)
+    L.call("edrl_conv2d_nhwc_dgrad_f32", P(dy), P(wt), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad,
+           Co, Ci, FLAG_ACCUM if accumulate else 0)
+    return out
+
+
+def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False):
+    N, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    KH, KW = w_shape[1], w_shape[2]
+    if out is None:
+        out = torch.empty(w_shape, device=dy.device, dtype=torch.float32)
+        accumulate = False
+    nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
+    ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+    L.call("edrl_conv2d_nhwc_wgrad_f32", P(dy), P(x), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW,
+           stride, pad, Co, Ci, 1 if accumulate else 0)
+    return out
+
+
+def linear_fwd(x2, w, bias=None, mul=None, relu=False):
+    """x2 [rows, in] (row stride allowed), w [out, in] -> [rows, out]."""
+    rows, cin = x2.shape
+    cout = w.shape[0]
+    out = torch.empty((rows, cout), device=x2.device, dtype=torch.float32)
+    L.call("edrl_conv2d_nhwc_fwd_f32", P(x2), P(w), P(bias), P(mul), P(out), rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0,
+           _ld(x2), cout, cout, FLAG_RELU if relu else 0)
+    return out
+
+
+def linear_dgrad(dy2, w):
+    """dy2 [rows, out], w [out, in] -> dx [rows, in]."""
+    rows, cout = dy2.shape
+    cin = w.shape[1]
+    wt = permute_weight(w)  # [in, out]
+    out = torch.empty((rows, cin), device=dy2.device, dtype=torch.float32)
+    L.call("edrl_conv2d_nhwc_dgrad_f32", P(dy2), P(wt), P(out), rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0,
+           _ld(dy2), cin, 0)
+    return out
+
+
+def matmul_tn(a2, b2):
+    """a2 [rows, M], b2 [rows, N] (row strides allowed) -> a2^T @ b2  [M, N] (split-K over rows)."""
+    rows, M = a2.shape
+    N = b2.shape[1]
+    out = torch.empty((M, N), device=a2.device, dtype=torch.float32)
+    nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", rows, 1, 1, M, N, 1, 1)
+    ws = torch.empty(max(nbytes // 4, 1), device=a2.device, dtype=torch.float32)
+    L.call("edrl_conv2d_nhwc_wgrad_f32", P(a2), P(b2), P(out), P(ws), nbytes, rows, 1, 1, N, 1, 1, M, 1, 1, 1, 0,
+           _ld(a2), _ld(b2), 0)
+    return out
+
+
+def sum_axis1(x3, scale=1.0):
+    A, Ln, D = x3.shape
+    out = torch.empty((A, D), device=x3.device, dtype=torch.float32)
+    L.call("edrl_sum_axis1_f32", P(x3), P(out), A, Ln, D, float(scale))
+    return out
+
+
+def bcast_axis1(x2, Ln, scale=1.0):
+    A, D = x2.shape
+    out = torch.empty((A, Ln, D), device=x2.device, dtype=torch.float32)
+    L.call("edrl_bcast_axis1_f32", P(x2), P(out), A, Ln, D, float(scale), 0)
+    return out
+
+
+def colsum(x2):
+    """[rows, D] -> [D]"""
+    x2 = x2.contiguous()
+    return sum_axis1(x2.view(1, x2.shape[0], x2.shape[1])).view(-1)
+
+
+# ------------------------------------------------------------------ autograd functions
+class LinearFn(torch.autograd.Function):
+    """y = (relu?)(x @ w^T + b) * mask   — nn.Linear (+ReLU +Dropout mask), fusion_net.py:82-90 etc."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, mask):
+        _chk(x, "linear.x", contiguous=False); _chk(w, "linear.w")
+        x2 = _rows2d(x)
+        m2 = None if mask is None else _chk(mask, "linear.mask").reshape(-1, w.shape[0])
+        y = linear_fwd(x2, w, b, m2, relu)
+        ctx.relu = relu
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x2, w, y if relu else None, m2)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y, m2 = ctx.saved_tensors
+        g = _rows2d(dy.contiguous())
+        if ctx.relu:
+            g = ew(EW_MASKED_BWD, g, m2, y)
+        elif m2 is not None:
+            g = ew(EW_MUL, g, m2)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(g, w).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = matmul_tn(g, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(g)
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b=None, relu=False, mask=None):
+    return LinearFn.apply(x, w, b, relu, mask)
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ew(EW_RELU, _chk(x, "relu.x", False))
+        ctx.save_for_backward(y)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ew(EW_RELU_BWD, dy.contiguous(), y).view(dy.shape)
+
+
+def relu(x):
+    return ReluFn.apply(x)
+
+
+class AddFn(torch.autograd.Function):
+    """a + b, optionally followed by ReLU (AttentionModel residuals, fusion_net.py:572,575-576)."""
+
+    @staticmethod
+    def forward(ctx, a, b, do_relu):
+        y = ew(EW_ADD_RELU if do_relu else EW_AXPBY, _chk(a, "add.a", False), _chk(b, "add.b", False).contiguous())
+        ctx.do_relu = do_relu
+        if do_relu:
+            ctx.save_for_backward(y)
+        return y.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.do_relu:
+            (y,) = ctx.saved_tensors
+            g = ew(EW_RELU_BWD, dy.contiguous(), y).view(dy.shape)
+            return g, g, None
+        return dy, dy, None
+
+
+def add(a, b, relu=False):
+    return AddFn.apply(a, b, relu)
+
+
+class SoftplusFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "softplus.x", False).contiguous()
+        ctx.save_for_backward(x)
+        return ew(EW_SOFTPLUS, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ew(EW_SOFTPLUS_BWD, dy.contiguous(), x)
+
+
+def softplus(x):
+    return SoftplusFn.apply(x)
+
+
+class L2NormAxis1Fn(torch.autograd.Function):
+    """F.normalize(x, dim=1) for x [A, L, D] (fusion_net.py:149-150)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _chk(x, "l2norm.x", False).contiguous()
+        A, Ln, D = x.shape
+        y = torch.empty_like(x)
+        inv = torch.empty((A, D), device=x.device, dtype=torch.float32)
+        L.call("edrl_l2norm_axis1_fwd_f32", P(x), P(y), P(inv), A, Ln, D, float(eps))
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        A, Ln, D = y.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        L.call("edrl_l2norm_axis1_bwd_f32", P(dy), P(y), P(inv), P(dx), A, Ln, D)
+        return dx, None
+
+
+def l2norm_axis1(x, eps=1e-12):
+    return L2NormAxis1Fn.apply(x, eps)
+
+
+class MeanAxis1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "mean.x", False).contiguous()
+        ctx.Ln = x.shape[1]
+        return sum_axis1(x, 1.0 / x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return bcast_axis1(dy.contiguous(), ctx.Ln, 1.0 / ctx.Ln)
+
+
+def mean_axis1(x):
+    return MeanAxis1Fn.apply(x)
+
+
+class RepeatAxis1Fn(torch.autograd.Function):
+    """[A, D] -> [A, L, D] (mu_proxy.repeat(B,1,1) is the A=1 case, fusion_net.py:246-247)."""
+
+    @staticmethod
+    def forward(ctx, x, Ln):
+        return bcast_axis1(_chk(x, "repeat.x", False).contiguous(), Ln)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return sum_axis1(dy.contiguous()), None
+
+
+def repeat_axis1(x, Ln):
+    return RepeatAxis1Fn.apply(x, Ln)
+
+
+class AffineBcastFn(torch.autograd.Function):
+    """out[a,l,d] = u[a,d] + v[a,d] * w[a,l,d]  (w = noise, no gradient)."""
+
+    @staticmethod
+    def forward(ctx, u, v, w):
+        u = _chk(u, "affine.u", False).contiguous(); v = _chk(v, "affine.v", False).contiguous()
+        w = _chk(w, "affine.w", False).contiguous()
+        A, Ln, D = w.shape
+        out = torch.empty_like(w)
+        L.call("edrl_affine_bcast_fwd_f32", P(u), P(v), P(w), P(out), A, Ln, D)
+        ctx.save_for_backward(w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (w,) = ctx.saved_tensors
+        A, Ln, D = w.shape
+        dout = dout.contiguous()
+        du = torch.empty((A, D), device=w.device, dtype=torch.float32)
+        dv = torch.empty_like(du)
+        L.call("edrl_affine_bcast_bwd_f32", P(dout), P(w), P(du), P(dv), A, Ln, D)
+        return du, dv, None
+
+
+def affine_bcast(u, v, w):
+    return AffineBcastFn.apply(u, v, w)
+
+
+class TopkMarginFn(torch.autograd.Function):
+    """EPRL proxy loss from attention scores (fusion_net.py:227-243). att [B,C,S], y int64 [B]."""
+
+    @staticmethod
+    def forward(ctx, att, y, K):
+        att = _chk(att, "topk.att", False).contiguous()
+        B, C, S = att.shape
+        sel = torch.zeros((B, C, S), device=att.device, dtype=torch.uint8)
+        means = torch.empty((B, 2), device=att.device, dtype=torch.float32)
+        e = torch.empty((B,), device=att.device, dtype=torch.float32)
+        loss = torch.empty((1,), device=att.device, dtype=torch.float32)
+        L.call("edrl_topk_margin_fwd_f32", P(att), P(y), P(sel), P(means), P(e), P(loss), B, C, S, K)
+        ctx.save_for_backward(sel, e, y)
+        ctx.dims = (B, C, S, K)
+        ctx.mark_non_differentiable(sel)
+        return loss.view(()), sel
+
+    @staticmethod
+    def backward(ctx, dloss, _dsel):
+        sel, e, y = ctx.saved_tensors
+        B, C, S, K = ctx.dims
+        datt = torch.empty((B, C, S), device=e.device, dtype=torch.float32)
+        dloss = dloss.contiguous().view(1)
+        L.call("edrl_topk_margin_bwd_f32", P(dloss), P(e), P(sel), P(y), P(datt), B, C, S, K)
+        return datt, None, None
+
+
+def topk_margin(att, y, K=100):
+    return TopkMarginFn.apply(att, y, K)
+
+
+class Poe2Fn(torch.autograd.Function):
+    """PoE.forward for two modalities (fusion_net.py:26-52): returns mu + var."""
+
+    @staticmethod
+    def forward(ctx, mu0, s0, mu1, s1, phi, eps):
+        ts = [_chk(t, "poe", False).contiguous() for t in (mu0, s0, mu1, s1)]
+        phi = _chk(phi, "poe.phi")
+        out = torch.empty_like(ts[0])
+        L.call("edrl_poe2_fwd_f32", P(ts[0]), P(ts[1]), P(ts[2]), P(ts[3]), P(phi), P(out), out.numel(), float(eps))
+        ctx.save_for_backward(*ts, phi)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu0, s0, mu1, s1, phi = ctx.saved_tensors
+        g = g.contiguous()
+        outs = [torch.empty_like(mu0) for _ in range(4)]
+        dphi = torch.empty_like(phi)
+        ws = torch.empty(128, device=g.device, dtype=torch.float32)
+        L.call("edrl_poe2_bwd_f32", P(g), P(mu0), P(s0), P(mu1), P(s1), P(phi), P(outs[0]), P(outs[1]), P(outs[2]),
+               P(outs[3]), P(dphi), P(ws), g.numel(), float(ctx.eps))
+        return outs[0], outs[1], outs[2], outs[3], dphi, None
+
+
+def poe2(mu0, s0, mu1, s1, phi, eps=1e-8):
+    return Poe2Fn.apply(mu0, s0, mu1, s1, phi, eps)
+
+
+class KlNormalFn(torch.autograd.Function):
+    """MedFusion.get_KL_loss (fusion_net.py:838-850, 390-402). mu, sg [B, C, D] -> scalar."""
+
+    @staticmethod
+    def forward(ctx, mu, sg):
+        mu = _chk(mu, "kl.mu", False).contiguous(); sg = _chk(sg, "kl.sg", False).contiguous()
+        Bn, C, D = mu.shape
+        loss = torch.empty((1,), device=mu.device, dtype=torch.float32)
+        ws = torch.empty(64, device=mu.device, dtype=torch.float32)
+        L.call("edrl_kl_normal_fwd_f32", P(mu), P(sg), P(loss), P(ws), Bn, C, D)
+        ctx.save_for_backward(mu, sg)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        mu, sg = ctx.saved_tensors
+        Bn, C, D = mu.shape
+        dmu = torch.empty_like(mu); dsg = torch.empty_like(sg)
+        dloss = dloss.contiguous().view(1)
+        L.call("edrl_kl_normal_bwd_f32", P(dloss), P(mu), P(sg), P(dmu), P(dsg), Bn, C, D)
+        return dmu, dsg
+
+
+def kl_normal(mu, sg):
+    return KlNormalFn.apply(mu, sg)
+
+
+class MhaCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) v per head. q [B,Lq,E], kv [B,N,2E] -> ctx [B,Lq,E]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H):
+        q = _chk(q, "mha.q", False).contiguous(); kv = _chk(kv, "mha.kv", False).contiguous()
+        B, Lq, E = q.shape
+        N = kv.shape[1]
+        Pm = torch.empty((B, H, Lq, N), device=q.device, dtype=torch.float32)
+        out = torch.empty_like(q)
+        L.call("edrl_mha_core_fwd_f32", P(q), P(kv), P(Pm), P(out), B, Lq, N, H, E)
+        ctx.save_for_backward(q, kv, Pm)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        q, kv, Pm = ctx.saved_tensors
+        B, Lq, E = q.shape
+        N = kv.shape[1]
+        dctx = dctx.contiguous()
+        dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+        L.call("edrl_mha_core_bwd_f32", P(dctx), P(q), P(kv), P(Pm), P(dq), P(dkv), B, Lq, N, ctx.H, E)
+        return dq, dkv, None
+
+
+def mha_core(q, kv, H):
+    return MhaCoreFn.apply(q, kv, H)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = _chk(x, "ln.x", False).contiguous()
+        E = x.shape[-1]
+        R = x.numel() // E
+        y = torch.empty_like(x)
+        mean = torch.empty((R,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        L.call("edrl_layernorm_fwd_f32", P(x), P(w), P(b), P(y), P(mean), P(rstd), R, E, float(eps))
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        E = x.shape[-1]
+        R = x.numel() // E
+        dy = dy.contiguous()
+        dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(w)
+        L.call("edrl_layernorm_bwd_f32", P(dy), P(x), P(w), P(mean), P(rstd), P(dx), P(dw), P(db), R, E)
+        return dx, dw, db, None
+
+
+def layernorm(x, w, b, eps=1e-5):
+    return LayerNormFn.apply(x, w, b, eps)
+
+
+def _bn_ws(M, C, device, extra=0):
+    nbytes = L.query("edrl_bn_workspace_bytes", M, C) + extra
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32), nbytes
+
+
+class BatchNorm1dTrainFn(torch.autograd.Function):
+    """Train-mode BatchNorm1d(affine=False) on [M, C]; `updates` running-stat updates per call
+    (DILR applies bn1/bn2 twice per forward to the same tensor: fusion_net.py:658,757-758)."""
+
+    @staticmethod
+    def forward(ctx, x, running_mean, running_var, momentum, eps, updates):
+        x = _chk(x, "bn.x", False).contiguous()
+        M, C = x.shape
+        mean = torch.empty((C,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean); scale = torch.empty_like(mean); shift = torch.empty_like(mean)
+        ws, nbytes = _bn_ws(M, C, x.device)
+        for _ in range(updates):
+            L.call("edrl_bn_train_stats_f32", P(x), M, C, C, None, None, P(running_mean), P(running_var),
+                   float(momentum), float(eps), P(mean), P(rstd), P(scale), P(shift), P(ws), nbytes)
+        y = torch.empty_like(x)
+        L.call("edrl_bn_apply_f32", P(x), P(scale), P(shift), None, P(y), M, C, C, 0)
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        M, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        ws, nbytes = _bn_ws(M, C, x.device, extra=2 * C * 4)
+        L.call("edrl_bn_bwd_f32", P(dy), None, P(x), P(mean), P(rstd), None, None, None, 0, P(dx), None, 0, M, C, C,
+               P(ws), nbytes)
+        return dx, None, None, None, None, None
+
+
+def batchnorm1d_train(x, running_mean, running_var, momentum=0.1, eps=1e-5, updates=1):
+    return BatchNorm1dTrainFn.apply(x, running_mean, running_var, momentum, eps, updates)
+
+
+class CrossCorrFn(torch.autograd.Function):
+    """c = scale * a^T @ b for column blocks a, b [rows, n] (row strides allowed)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a2 = _rows2d(_chk(a, "xcorr.a", False)); b2 = _rows2d(_chk(b, "xcorr.b", False))
+        c = matmul_tn(a2, b2)
+        if scale != 1.0:
+            c = ew(EW_SCALE, c, alpha=scale)
+        ctx.save_for_backward(a2, b2)
+        ctx.scale = scale
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a2, b2 = ctx.saved_tensors
+        dcs = ew(EW_SCALE, dc.contiguous(), alpha=ctx.scale)
+        # da[r][i] = sum_j dc[i][j] b[r][j] ;  db[r][j] = sum_i dc[i][j] a[r][i]
+        da = linear_fwd(b2, dcs)
+        db = linear_fwd(a2, permute_weight(dcs))
+        return da, db, None
+
+
+def cross_corr(a, b, scale):
+    return CrossCorrFn.apply(a, b, scale)
+
+
+class BtLossFn(torch.autograd.Function):
+    """(loss_c + loss_u)/2 of DILR.bt_loss_cross given the two diagonal blocks of c (fusion_net.py:664-677,754)."""
+
+    @staticmethod
+    def forward(ctx, cc, cu, lambd):
+        cc = _chk(cc, "bt.cc"); cu = _chk(cu, "bt.cu")
+        n = cc.shape[0]
+        out = torch.empty(7, device=cc.device, dtype=torch.float32)
+        ws = torch.empty(512, device=cc.device, dtype=torch.float32)
+        L.call("edrl_bt_loss_fwd_f32", P(cc), P(cu), n, float(lambd), P(out), P(ws))
+        ctx.save_for_backward(cc, cu)
+        ctx.lambd = lambd
+        ctx.mark_non_differentiable(out)
+        return out[6].clone(), out
+
+    @staticmethod
+    def backward(ctx, dloss, _dparts):
+        cc, cu = ctx.saved_tensors
+        n = cc.shape[0]
+        dcc = torch.empty_like(cc); dcu = torch.empty_like(cu)
+        dloss = dloss.contiguous().view(1)
+        L.call("edrl_bt_loss_bwd_f32", P(dloss), P(cc), P(cu), P(dcc), P(dcu), n, float(ctx.lambd))
+        return dcc, dcu, None
+
+
+def bt_loss(cc, cu, lambd=0.0051):
+    return BtLossFn.apply(cc, cu, lambd)
+
+
+class SmoothCeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, y, smoothing):
+        pred = _chk(pred, "ce.pred", False).contiguous()
+        B, C = pred.shape
+        loss = torch.empty((1,), device=pred.device, dtype=torch.float32)
+        L.call("edrl_smooth_ce_fwd_f32", P(pred), P(y), P(loss), B, C, float(smoothing))
+        ctx.save_for_backward(pred, y)
+        ctx.smoothing = smoothing
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pred, y = ctx.saved_tensors
+        B, C = pred.shape
+        dpred = torch.empty_like(pred)
+        dloss = dloss.contiguous().view(1)
+        L.call("edrl_smooth_ce_bwd_f32", P(dloss), P(pred), P(y), P(dpred), B, C, float(ctx.smoothing))
+        return dpred, None, None
+
+
+def smooth_ce(pred, y, smoothing=0.1):
+    return SmoothCeFn.apply(pred, y, smoothing)
+
+
+def argmax_rows(x):
+    x = _chk(x.detach(), "argmax.x", False).contiguous()
+    out = torch.empty((x.shape[0],), device=x.device, dtype=torch.int64)
+    L.call("edrl_argmax_rows_f32", P(x), P(out), x.shape[0], x.shape[1])
+    return out
+
+
+class ScalarMixFn(torch.autograd.Function):
+    """sum_i w_i * s_i over 0-d tensors (loss mixers, fusion_net.py:870-879; fusion_train.py:212)."""
+
+    @staticmethod
+    def forward(ctx, weights, *scalars):
+        import ctypes
+        n = len(scalars)
+        ss = [_chk(s, "mix.s", False).contiguous() for s in scalars]
+        ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in ss])
+        ws = (ctypes.c_float * n)(*[float(w) for w in weights])
+        out = torch.empty((1,), device=ss[0].device, dtype=torch.float32)
+        L.call("edrl_scalar_mix_f32", ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(ws, ctypes.c_void_p), n, P(out))
+        ctx.weights = [float(w) for w in weights]
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().view(1)
+        return (None,) + tuple(ew(EW_SCALE, g, alpha=w).view(()) for w in ctx.weights)
+
+
+def scalar_mix(weights, scalars):
+    return ScalarMixFn.apply(tuple(weights), *scalars)
+
+
+class MkMmdFn(torch.autograd.Function):
+    """MK_MMD(source, target, kernel_mul, kernel_num)  (code/MMD.py:46-74)."""
+
+    @staticmethod
+    def forward(ctx, source, target, kernel_mul, kernel_num):
+        _chk(source, "mmd.source", False); _chk(target, "mmd.target", False)
+        total = torch.cat([source, target], dim=0).contiguous()
+        n, d = total.shape
+        ns = source.shape[0]
+        G = linear_fwd(total, total)
+        sq = torch.empty((n,), device=total.device, dtype=torch.float32)
+        L.call("edrl_rowsq_f32", P(total), P(sq), n, d, d)
+        loss = torch.empty((1,), device=total.device, dtype=torch.float32)
+        saved = torch.empty((3,), device=total.device, dtype=torch.float32)
+        L.call("edrl_mk_mmd_fwd_f32", P(G), P(sq), n, ns, float(kernel_mul), int(kernel_num), P(loss), P(saved))
+        ctx.save_for_backward(total, G, sq, saved)
+        ctx.cfg = (ns, float(kernel_mul), int(kernel_num))
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        total, G, sq, saved = ctx.saved_tensors
+        ns, mul, num = ctx.cfg
+        n, d = total.shape
+        dloss = dloss.contiguous().view(1)
+        ws = torch.empty((n, n), device=total.device, dtype=torch.float32)
+        coef = torch.empty((n, n), device=total.device, dtype=torch.float32)
+        L.call("edrl_mk_mmd_bwd_f32", P(dloss), P(G), P(sq), P(saved), n, ns, mul, num, P(ws), P(coef))
+        dtotal = linear_fwd(coef, permute_weight(total))  # coef [n,n] @ total [n,d]
+        return dtotal[:ns], dtotal[ns:], None, None
+
+
+def mk_mmd(source, target, kernel_mul=2.0, kernel_num=5):
+    return MkMmdFn.apply(source, target, kernel_mul, kernel_num)

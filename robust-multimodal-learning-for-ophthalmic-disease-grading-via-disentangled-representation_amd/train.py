@@ -1,0 +1,62 @@
+"""The optimisation step of the reference driver, `fusion_train.train()` (fusion_train.py:166-265).
+
+Call order reproduced exactly (fusion_train.py:189-224):
+    optimizer.zero_grad() -> model(low view) -> model(high view) [its pred/loss discarded, Q12]
+    -> MK_MMD(cf1, cf2) -> loss + loss_MDD -> argmax predictions -> backward -> optimizer.step()
+The per-iteration host syncs of the reference (`.cpu()`, `.item()`, fusion_train.py:214-225) are
+not part of the contract: metrics stay on the device and are pulled by the caller.
+"""
+import torch
+
+from . import ops
+from .mmd import MK_MMD
+
+
+def synthetic_batch(batch, H=224, W=224, S=32, device="cuda", seed=1234, rank=0, drop_oct_high=False):
+    """Synthetic twin-view batch: low view ~U[0,1); high view = clip(low + N(0,0.5^2), 0, 1)
+    (mirrors data_harvard.py:769-783); OCT-dropped high view = zeros (data_harvard.py:333-334)."""
+    g = torch.Generator().manual_seed(seed + rank)
+    f_low = torch.rand(batch, 3, H, W, generator=g)
+    o_low = torch.rand(batch, 1, S, H, W, generator=g)
+    f_high = (f_low + 0.5 * torch.randn(f_low.shape, generator=g)).clamp_(0, 1)
+    if drop_oct_high:
+        o_high = torch.zeros_like(o_low)
+    else:
+        o_high = (o_low + 0.5 * torch.randn(o_low.shape, generator=g)).clamp_(0, 1)
+    y = torch.randint(0, 2, (batch,), generator=g, dtype=torch.int64)
+    dev = torch.device(device)
+    return ([f_low.to(dev), o_low.to(dev)], [f_high.to(dev), o_high.to(dev)]), y.to(dev)
+
+
+def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None, grad_sync=None):
+    """One iteration of the loop body at fusion_train.py:176-225. Returns device tensors, no host sync.
+    `grad_sync` (optional): called after backward, before optimizer.step (DP gradient all-reduce)."""
+    data1, data2 = data
+    optimizer.zero_grad()
+    pred, loss, combined_features1 = model(data1, target, epoch, noise=noise1)
+    _, _, combined_features2 = model(data2, target, epoch, noise=noise2)
+    loss_MDD = MK_MMD(combined_features1, combined_features2)
+    total = ops.scalar_mix([1.0, 1.0], [loss, loss_MDD])
+    predicted = ops.argmax_rows(pred)
+    total.backward()
+    if grad_sync is not None:
+        grad_sync()
+    optimizer.step()
+    return {"loss": total.detach(), "loss_MDD": loss_MDD.detach(), "pred": pred.detach(), "predicted": predicted}
+
+
+def train(epoch, train_loader, model, optimizer, log_every=0):
+    """fusion_train.train(): iterate the loader, accumulate accuracy/loss (pulled once at the end)."""
+    model.train()
+    correct = torch.zeros((), device=next(model.parameters()).device, dtype=torch.int64)
+    loss_sum = torch.zeros((), device=correct.device)
+    n_batches, n_seen = 0, 0
+    for data, target in train_loader:
+        out = train_step(model, optimizer, data, target, epoch)
+        correct += (out["predicted"] == target).sum()
+        loss_sum += out["loss"]
+        n_batches += 1
+        n_seen += target.shape[0]
+    if hasattr(model, "raise_on_bad_labels"):
+        model.raise_on_bad_labels()
+    return {"loss": (loss_sum / max(n_batches, 1)).item(), "acc": correct.item() / max(n_seen, 1)}
