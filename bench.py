@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — EDRL training-step throughput on MI355X (contract: see the task's bench.py section).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C0|C2x] [--batch B]
+  N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic batch: zero_grad -> forward(low view) ->
+forward(high view) -> MK_MMD -> backward -> (DP gradient all-reduce) -> Adam.step
+(fusion_train.py:189-224).  Inputs are resident in HBM before the timed region.  Workload at N=1 is
+BASELINE.json configs[1] (C1): per-GPU batch 32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (per-GPU batch, encoder depth, H=W, slices, description)
+    "C0": (2, 18, 224, 16, "C0: B=2/GPU, ResNet-18 encoders, 224x224 fundus + 16-slice OCT, fp32"),
+    "C1": (32, 50, 224, 32, "C1: B=32/GPU, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C1", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (diagnostics only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import edrl_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, depth, HW, S, desc = CONFIGS[a.config]
+    if a.batch:
+        B = a.batch
+        desc = desc.replace(f"B={CONFIGS[a.config][0]}/GPU", f"B={B}/GPU (override)")
+    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, strict_labels=False)
+    torch.manual_seed(0)
+    model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
+    edrl_amd.broadcast_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    sync = edrl_amd.GradSync(model) if world > 1 else None
+    data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank)
+
+    def step():
+        return edrl_amd.train_step(model, opt, data, y, grad_sync=sync.finish if sync else None)
+
+    for _ in range(a.warmup):
+        step()
+    timer = None
+    if not a.no_kernel_timing and rank == 0:
+        timer = edrl_amd.ops.KernelTimer()
+        edrl_amd.ops.set_timer(timer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    edrl_amd.ops.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = out["loss"].item()
+    model.raise_on_bad_labels()
+    assert loss == loss, "NaN loss"
+
+    if rank == 0:
+        value = B * world * a.steps / dt
+        res = {
+            "metric": "train images/sec (fundus+OCT pair)", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": desc, "global_batch": B * world, "per_gpu_batch": B, "encoder": f"resnet{depth}",
+                       "fundus": [3, HW, HW], "oct": [1, S, HW, HW], "parallelism": f"dp{world}",
+                       "optimizer": "Adam(lr=1e-4, weight_decay=1e-6)"},
+            "final_loss": loss,
+            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        }
+        if timer is not None:
+            ks = timer.summary()
+            dom = ks.get("conv_gather")
+            if dom:
+                avg_ms = dom["ms"] / dom["launches"]
+                res["roofline"] = {
+                    "kernel": "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)",
+                    "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+                    "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
+                }
+            res["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
+                                  "tflops": round(v["tflops"], 3)} for k, v in ks.items()}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(model, depth, HW, S)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, depth, HW, S):
+    """The oracle (torch-CPU restatement, `kind: port`) timed on this host on a bounded sample of the same
+    workload: ONE step at per-step batch 2 (the smallest batch train-mode BatchNorm admits) of the same
+    shapes/encoders."""
+    import torch
+    import edrl_amd
+    from oracle import step_oracle as SO
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc = 2
+    orc = SO.OracleEDRL(model, dtype=torch.float32)
+    orc.batch_size = Bc
+    data, y = edrl_amd.synthetic_batch(Bc, HW, HW, S, device="cpu", seed=99)
+    N2 = (HW // 32) ** 2
+    n1, n2 = SO.make_noise(1, Bc, N2, S), SO.make_noise(2, Bc, N2, S)
+    t0 = time.perf_counter()
+    orc.train_step(data, y, n1, n2, lr=1e-4, adam_state={})
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full step (2 views fwd+bwd + MK_MMD + Adam) at batch {Bc}, resnet{depth}, {HW}x{HW} + {S} slices, "
+                      f"torch-CPU fp32 oracle, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""CPU oracle of the whole optimisation step — TEST INFRASTRUCTURE ONLY.
+
+Composes oracle/resnet_oracle.py (encoders; parity unpinned by the reference, see that file) with
+oracle/edrl_oracle.py (head + MK-MMD, pinned against the reference) in the call order of
+fusion_train.py:189-224.  Parameters are taken by name from a product model's state (copied to
+the CPU), so product and oracle start from identical weights.  Also the `cpu_baseline` of bench.py.
+"""
+import torch
+
+from . import edrl_oracle as O
+from . import resnet_oracle as RO
+
+
+class OracleEDRL:
+    def __init__(self, product_model, dtype=torch.float32):
+        self.dtype = dtype
+        self.batch_size = product_model.args.batch_size
+        self.enc = {}
+        for key in ("transformer_2DNet", "transformer_3DNet"):
+            m = getattr(product_model, key)
+            self.enc[key] = {"sd": RO.trunk_state(m.trunk, dtype=dtype), "kind": m.trunk.kind, "blocks": m.trunk.blocks,
+                             "w": m.token_proj.weight.detach().cpu().to(dtype).requires_grad_(True),
+                             "b": m.token_proj.bias.detach().cpu().to(dtype).requires_grad_(True)}
+        self.p = {}
+        shapes = O.head_param_shapes()
+        for n, t in product_model.named_parameters():
+            if n in shapes:
+                self.p[n] = t.detach().cpu().to(dtype).requires_grad_(True)
+        assert set(self.p) == set(shapes)
+        self.state = O.make_bn_state(dtype)
+        for n in ("DILR.bn1", "DILR.bn2"):
+            for s in (".running_mean", ".running_var"):
+                self.state[n + s] = product_model.state_dict()[n + s].detach().cpu().to(dtype).clone()
+
+    def parameters(self):
+        """name (product naming) -> tensor, for every tensor that receives a gradient."""
+        out = dict(self.p)
+        for key, e in self.enc.items():
+            for n, t in e["sd"].items():
+                if t.dtype.is_floating_point and t.requires_grad:
+                    out[f"{key}.trunk.{n}"] = t
+            out[f"{key}.token_proj.weight"] = e["w"]
+            out[f"{key}.token_proj.bias"] = e["b"]
+        return out
+
+    def forward(self, X, y, noise):
+        f, o = self.enc["transformer_2DNet"], self.enc["transformer_3DNet"]
+        x, _ = RO.fundus_encoder_forward(X[0].to(self.dtype), f["sd"], f["kind"], f["blocks"], f["w"], f["b"])
+        x1, _ = RO.oct_encoder_forward(X[1].to(self.dtype), o["sd"], o["kind"], o["blocks"], o["w"], o["b"])
+        return O.medfusion_forward_tokens(self.p, self.state, x, x1, y, noise, self.batch_size)
+
+    def train_step(self, data, y, noise1, noise2, lr=None, adam_state=None):
+        params = self.parameters()
+        for t in params.values():
+            t.grad = None
+        pred, loss, cf1, aux = self.forward(data[0], y, noise1)
+        _, _, cf2, _ = self.forward(data[1], y, noise2)
+        loss_mdd = O.MK_MMD(cf1, cf2)
+        total = loss + loss_mdd
+        total.backward()
+        grads = {n: t.grad for n, t in params.items()}
+        if lr is not None:
+            with torch.no_grad():
+                O.adam_step(params, grads, adam_state, lr)
+        return {"pred": pred, "loss": loss, "cf1": cf1, "cf2": cf2, "loss_MDD": loss_mdd, "total": total,
+                "predicted": pred.argmax(-1), "grads": grads}
+
+
+def make_noise(seed, B, N2, N3, dtype=torch.float32):
+    """RNG-derived tensors of one forward (same layout as edrl_oracle.make_head_inputs's noise)."""
+    _, _, _, noise = O.make_head_inputs(seed, B, N2, N3, dtype)
+    return noise

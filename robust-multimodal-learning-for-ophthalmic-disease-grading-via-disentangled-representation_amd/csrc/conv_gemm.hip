@@ -308,7 +308,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
       const long p = p0 + row;
       const int co = co0 + ac4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p < g.P && co < g.Co) v = *reinterpret_cast<const f32x4*>(dy + p * g.ld_dy + co);
+      if (VEC) {
+        if (p < g.P && co < g.Co) v = *reinterpret_cast<const f32x4*>(dy + p * g.ld_dy + co);
+      } else if (p < g.P) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < g.Co) v[e] = dy[p * g.ld_dy + co + e];
+      }
       a_st[i] = v;
     }
 #pragma unroll
@@ -533,8 +539,6 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
   if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
   const bool vec = (Ci % 4 == 0) && (ld_x % 4 == 0) && (Co % 4 == 0) && (ld_dy % 4 == 0) &&
                    (((uintptr_t)dy & 15) == 0) && (((uintptr_t)x & 15) == 0);
-  // the dY operand is always read as float4: require it
-  if ((Co % 4) || (ld_dy % 4) || ((uintptr_t)dy & 15)) return EDRL_EINVAL;
   int rc;
   if (bm == 64 && bn == 64)
     rc = vec ? launch_wgrad<64, 64, true>(dy, x, workspace, g, splits, st)

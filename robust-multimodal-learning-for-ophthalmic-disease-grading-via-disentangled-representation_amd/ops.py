@@ -39,6 +39,48 @@ def _ld(x2):
     return x2.stride(0) if x2.shape[0] > 1 else max(x2.stride(0), x2.shape[1])
 
 
+# ------------------------------------------------------------------ live kernel timing (bench.py roofline leg)
+class KernelTimer:
+    """HIP-event bracketing of the MFMA contraction launches on the stream they run on.
+    kind -> [algorithmic flops, [(start_event, end_event), ...]]."""
+
+    def __init__(self):
+        self.records = {}
+
+    def add(self, kind, flops, e0, e1):
+        r = self.records.setdefault(kind, [0.0, []])
+        r[0] += flops
+        r[1].append((e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, (flops, evs) in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            out[kind] = {"launches": len(evs), "flops": flops, "ms": ms,
+                         "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+def _launch_timed(kind, flops, name, *args):
+    if _timer is None:
+        L.call(name, *args)
+        return
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.call(name, *args)
+    e1.record()
+    _timer.add(kind, flops, e0, e1)
+
+
 # ------------------------------------------------------------------ raw (non-autograd) launch helpers
 def ew(op, a, b=None, c=None, out=None, alpha=1.0, beta=1.0):
     a = a.contiguous()
@@ -57,8 +99,8 @@ def conv2d_fwd(x, w, bias=None, mul=None, stride=1, pad=0, relu=False, out=None,
     if out is None:
         out = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.float32)
     flags = (FLAG_RELU if relu else 0) | (FLAG_ACCUM if accumulate else 0)
-    L.call("edrl_conv2d_nhwc_fwd_f32", P(x), P(w), P(bias), P(mul), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW,
-           stride, pad, Ci, Co, Co, flags)
+    _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_f32", P(x), P(w), P(bias),
+                  P(mul), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Ci, Co, Co, flags)
     return out
 
 
@@ -81,8 +123,8 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=False):
     KH, KW = wt.shape[1], wt.shape[2]
     if out is None:
         out = torch.empty((N, Hi, Wi, Ci), device=dy.device, dtype=torch.float32)
-    L.call("edrl_conv2d_nhwc_dgrad_f32", P(dy), P(wt), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad,
-           Co, Ci, FLAG_ACCUM if accumulate else 0)
+    _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_f32", P(dy), P(wt),
+                  P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, FLAG_ACCUM if accumulate else 0)
     return out
 
 
@@ -95,8 +137,8 @@ def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False):
         accumulate = False
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
     ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
-    L.call("edrl_conv2d_nhwc_wgrad_f32", P(dy), P(x), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW,
-           stride, pad, Co, Ci, 1 if accumulate else 0)
+    _launch_timed("conv_wgrad", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_f32", P(dy), P(x),
+                  P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, 1 if accumulate else 0)
     return out
 
 
@@ -105,8 +147,8 @@ def linear_fwd(x2, w, bias=None, mul=None, relu=False):
     rows, cin = x2.shape
     cout = w.shape[0]
     out = torch.empty((rows, cout), device=x2.device, dtype=torch.float32)
-    L.call("edrl_conv2d_nhwc_fwd_f32", P(x2), P(w), P(bias), P(mul), P(out), rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0,
-           _ld(x2), cout, cout, FLAG_RELU if relu else 0)
+    _launch_timed("linear_gather", 2.0 * rows * cin * cout, "edrl_conv2d_nhwc_fwd_f32", P(x2), P(w), P(bias), P(mul),
+                  P(out), rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0, _ld(x2), cout, cout, FLAG_RELU if relu else 0)
     return out
 
 
@@ -116,8 +158,8 @@ def linear_dgrad(dy2, w):
     cin = w.shape[1]
     wt = permute_weight(w)  # [in, out]
     out = torch.empty((rows, cin), device=dy2.device, dtype=torch.float32)
-    L.call("edrl_conv2d_nhwc_dgrad_f32", P(dy2), P(wt), P(out), rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0,
-           _ld(dy2), cin, 0)
+    _launch_timed("linear_gather", 2.0 * rows * cin * cout, "edrl_conv2d_nhwc_dgrad_f32", P(dy2), P(wt), P(out), rows,
+                  1, 1, cin, 1, 1, cout, 1, 1, 1, 0, _ld(dy2), cin, 0)
     return out
 
 
@@ -128,8 +170,8 @@ def matmul_tn(a2, b2):
     out = torch.empty((M, N), device=a2.device, dtype=torch.float32)
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", rows, 1, 1, M, N, 1, 1)
     ws = torch.empty(max(nbytes // 4, 1), device=a2.device, dtype=torch.float32)
-    L.call("edrl_conv2d_nhwc_wgrad_f32", P(a2), P(b2), P(out), P(ws), nbytes, rows, 1, 1, N, 1, 1, M, 1, 1, 1, 0,
-           _ld(a2), _ld(b2), 0)
+    _launch_timed("linear_wgrad", 2.0 * rows * M * N, "edrl_conv2d_nhwc_wgrad_f32", P(a2), P(b2), P(out), P(ws), nbytes,
+                  rows, 1, 1, N, 1, 1, M, 1, 1, 1, 0, _ld(a2), _ld(b2), 0)
     return out
 
 

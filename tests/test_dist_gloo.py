@@ -1,0 +1,88 @@
+"""CPU, world_size 2, gloo: the DP gradient exchange (GradSync) — bucketing, hook-driven launches after the
+first step, dead parameters skipped, two forwards sharing weights, and N-rank averaged gradients equal to the
+single-process gradients on the concatenated batch for batch-decoupled losses."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(16, 32)
+        self.b = nn.Linear(32, 8)
+        self.dead = nn.Linear(4, 4)          # never used: must stay out of the buckets
+        self.c = nn.Linear(8, 1)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def _loss(net, x1, x2):
+    # two forwards share the weights (fusion_train.py:191,194); per-sample mean -> batch-decoupled
+    return net(x1).pow(2).mean() + 0.5 * net(x2).abs().mean()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import edrl_amd
+    torch.manual_seed(0)
+    net = Net()
+    edrl_amd.broadcast_parameters(net)
+    sync = edrl_amd.GradSync(net, bucket_mb=0.001)     # tiny buckets -> several collectives
+    g = torch.Generator().manual_seed(5)
+    X1, X2 = torch.randn(3, 8, 16, generator=g), torch.randn(3, 8, 16, generator=g)   # 3 steps, global batch 8
+    per = 8 // world
+    res = []
+    for step in range(3):
+        net.zero_grad()
+        x1, x2 = X1[step, rank * per:(rank + 1) * per], X2[step, rank * per:(rank + 1) * per]
+        _loss(net, x1, x2).backward()
+        sync.finish()
+        res.append({n: p.grad.numpy().copy() for n, p in net.named_parameters() if p.grad is not None})
+    q.put((rank, res, len(sync.buckets), sync.total_bytes()))
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    outs.sort(key=lambda o: o[0])
+    torch.manual_seed(0)
+    net = Net()
+    g = torch.Generator().manual_seed(5)
+    X1, X2 = torch.randn(3, 8, 16, generator=g), torch.randn(3, 8, 16, generator=g)
+    live_bytes = sum(p.numel() * 4 for n, p in net.named_parameters() if not n.startswith("dead"))
+    for rank, res, nb, nbytes in outs:
+        assert nb > 1, "expected several buckets"
+        assert nbytes == live_bytes, "dead parameters must not be exchanged"
+        for step in range(3):
+            net.zero_grad()
+            _loss(net, X1[step], X2[step]).backward()
+            assert "dead.weight" not in res[step]
+            for n, p in net.named_parameters():
+                if p.grad is None:
+                    continue
+                torch.testing.assert_close(torch.from_numpy(res[step][n]), p.grad, rtol=1e-5, atol=1e-6)

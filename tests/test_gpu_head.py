@@ -1,0 +1,162 @@
+"""GPU parity of the EDRL head (MedFusion.forward_tokens + MK_MMD + backward) against
+ (a) the fixtures captured from the real reference (tests/golden/head_step_*.npz) and
+ (b) the CPU oracle run on the same seeded inputs (elementwise gradients).
+Tolerances (fp32): logits 1e-4 relative (north_star), features 1e-4, losses 1e-4,
+gradients 2e-3 relative to each tensor's max (B=2 batch-norm is ill-conditioned), index ops bit-exact."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import edrl_oracle as O
+from util import check
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def to_dev(o, dev):
+    if isinstance(o, dict):
+        return {k: to_dev(v, dev) for k, v in o.items()}
+    return o.to(dev)
+
+
+def build(edrl, dev, B, seed):
+    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=18)
+    torch.manual_seed(0)
+    m = edrl.MedFusion(2, 2, None, args)
+    missing, unexpected = m.load_state_dict(O.make_head_params(seed), strict=False)
+    assert not unexpected
+    return m.to(dev).train()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "b8", "refdims"])
+def test_head_step_vs_reference_fixture_and_oracle(edrl, dev, tag):
+    z = np.load(os.path.join(GOLD, f"head_step_{tag}.npz"))
+    B, N2, N3, seed = int(z["B"]), int(z["N2"]), int(z["N3"]), int(z["seed"])
+    m = build(edrl, dev, B, seed)
+    xa, x1a, y, na = O.make_head_inputs(seed + 1, B, N2, N3)
+    xb, x1b, _, nb = O.make_head_inputs(seed + 2, B, N2, N3)
+    yd = y.to(dev)
+    pred, loss, cf1 = m.forward_tokens(xa.to(dev), x1a.to(dev), yd, to_dev(na, dev))
+    _, _, cf2 = m.forward_tokens(xb.to(dev), x1b.to(dev), yd, to_dev(nb, dev))
+    mmd = edrl.MK_MMD(cf1, cf2)
+    total = edrl.ops.scalar_mix([1.0, 1.0], [loss, mmd])
+    total.backward()
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    # yardsticks: the oracle in fp64 (truth) and in fp32 (the round-off envelope of the reference's own dtype;
+    # train-mode BatchNorm1d over B=2 rows is ill-conditioned, so the envelope can exceed 1e-4 there)
+    cast = lambda o: {k: cast(v) for k, v in o.items()} if isinstance(o, dict) else o.double()
+    p = {n: v.double().requires_grad_(True) for n, v in O.make_head_params(seed).items()}
+    res = O.head_train_step(p, O.make_bn_state(torch.float64), (xa.double(), x1a.double(), cast(na)),
+                            (xb.double(), x1b.double(), cast(nb)), y, B)
+    p32 = {n: v.clone().requires_grad_(True) for n, v in O.make_head_params(seed).items()}
+    r32 = O.head_train_step(p32, O.make_bn_state(), (xa, x1a, na), (xb, x1b, nb), y, B)
+    from util import relerr
+    env = max(relerr(r32["cf1"], res["cf1"]), relerr(r32["cf2"], res["cf2"]), relerr(r32["pred"], res["pred"]))
+    print(f"[parity] {tag}: fp32-CPU-oracle vs fp64 envelope (cf/pred) {env:.3e}")
+    tol = max(1e-4, 5 * env)
+    check(f"{tag}.pred(logits)", pred.cpu(), T(z["pred"]), tol)
+    check(f"{tag}.cf1", cf1.cpu(), T(z["cf1"]), tol)
+    check(f"{tag}.cf2", cf2.cpu(), T(z["cf2"]), tol)
+    check(f"{tag}.loss", loss.cpu().view(1), T([float(z["loss"])]).float(), tol)
+    check(f"{tag}.loss_MDD", mmd.cpu().view(1), T([float(z["loss_MDD"])]).float(), 5 * tol)
+    check(f"{tag}.total", total.cpu().view(1), T([float(z["total"])]).float(), 2 * tol)
+    assert torch.equal(edrl.ops.argmax_rows(pred).cpu(), T(z["predicted"])), "argmax must be bit exact"
+    check(f"{tag}.bn1.running_var", m.DILR.bn1.running_var.cpu(), T(z["bn1_running_var"]), 1e-4)
+    check(f"{tag}.bn2.running_mean", m.DILR.bn2.running_mean.cpu(), T(z["bn2_running_mean"]), 1e-4)
+    assert int(m.DILR.bn1.num_batches_tracked) == 4
+    named = dict(m.named_parameters())
+    names = [str(n) for n in z["grad_names"]]
+    got = np.array([named[n].grad.double().norm().item() for n in names])
+    genv = max(abs(r32["grads"][n].double().norm().item() / max(res["grads"][n].norm().item(), 1e-30) - 1) for n in names)
+    np.testing.assert_allclose(got, z["grad_norms"], rtol=max(2e-3, 5 * genv), atol=1e-8)
+    check(f"{tag}.pred_vs_fp64", pred.cpu(), res["pred"], tol)
+    worst = 0.0
+    for n in names:
+        g, r = named[n].grad.cpu().double(), res["grads"][n]
+        sc = r.abs().max().clamp_min(1e-12)
+        e = ((g - r).abs().max() / sc).item()
+        e32 = ((r32["grads"][n].double() - r).abs().max() / sc).item()
+        worst = max(worst, e)
+        assert e < max(2e-3, 5 * e32), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
+    print(f"[parity] {tag}: worst elementwise grad rel err vs fp64 oracle {worst:.3e}")
+    # dead parameters stay without gradient, exactly as in the reference
+    for n in ("EPRL_fundus.alpha", "EPRL_fundus.decoder_logits.weight", "EPRL_oct.mlp_3d.1.weight"):
+        assert named[n].grad is None, n
+
+
+def test_topk_selection_bit_exact_vs_reference_fixture(edrl, dev):
+    z = np.load(os.path.join(GOLD, "head_step_b8.npz"))
+    B, N2, N3, seed = int(z["B"]), int(z["N2"]), int(z["N3"]), int(z["seed"])
+    p = O.make_head_params(seed)
+    x, x1, y, noise = O.make_head_inputs(seed + 1, B, N2, N3)
+    _, _, _, _, aux = O.eprl_forward_train(p, "EPRL_oct.", x1, y, noise["oct"]["eps"], noise["oct"]["mask1"],
+                                           noise["oct"]["mask2"], B)
+    att = aux["att"].to(dev)
+    loss, sel = edrl.ops.topk_margin(att, y.to(dev), 100)
+    sel = sel.cpu().bool()
+    ref = torch.zeros(B, 2, 800, dtype=torch.bool)
+    pos, neg = torch.from_numpy(z["sel_oct_pos"]), torch.from_numpy(z["sel_oct_neg"])
+    for b in range(B):
+        ref[b, int(y[b]), pos[b]] = True
+        ref[b, 1 - int(y[b]), neg[b]] = True
+    assert torch.equal(sel, ref), "essence-point index set must equal the reference's topk indices"
+
+
+def test_bad_label_raises_like_reference(edrl, dev):
+    m = build(edrl, dev, 2, 5)
+    x, x1, y, noise = O.make_head_inputs(6, 2, 9, 6)
+    with pytest.raises(KeyError):
+        m.check_labels(torch.tensor([0, 3], device=dev))
+    with pytest.raises(RuntimeError):
+        m.forward_tokens(x[:1].to(dev), x1[:1].to(dev), y[:1].to(dev), to_dev(noise, dev))   # Q9: batch != args.batch_size
+
+
+def test_full_train_step_vs_oracle(edrl, dev):
+    """Row T1: two encoder forwards + head x2 + MK_MMD + backward + Adam on (B=2, R18, 64x64, S=4)."""
+    from oracle import step_oracle as SO
+    args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
+    torch.manual_seed(0)
+    m = edrl.MedFusion(2, 2, None, args).to(dev).train()
+    orc = SO.OracleEDRL(m, dtype=torch.float64)
+    data, y = edrl.synthetic_batch(2, 64, 64, 4, device="cpu")
+    N2, N3 = 4, 4
+    n1, n2 = SO.make_noise(50, 2, N2, N3), SO.make_noise(51, 2, N2, N3)
+    cast = lambda o: {k: cast(v) for k, v in o.items()} if isinstance(o, dict) else o.double()
+    ref = orc.train_step(([data[0][0].double(), data[0][1].double()], [data[1][0].double(), data[1][1].double()]), y,
+                         cast(n1), cast(n2))
+    r32 = SO.OracleEDRL(m, dtype=torch.float32).train_step(data, y, n1, n2)
+    from util import relerr
+    env = max(relerr(r32["pred"], ref["pred"]), relerr(r32["total"].view(1), ref["total"].view(1)))
+    print(f"[parity] full step: fp32-CPU-oracle vs fp64 envelope (pred/loss) {env:.3e}")
+    tol = max(1e-4, 5 * env)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    ddev = ([t.to(dev) for t in data[0]], [t.to(dev) for t in data[1]])
+    out = edrl.train_step(m, opt, ddev, y.to(dev), noise1=to_dev(n1, dev), noise2=to_dev(n2, dev))
+    check("step.pred(logits)", out["pred"].cpu(), ref["pred"], tol)
+    check("step.loss", out["loss"].cpu().view(1), ref["total"].view(1), tol)
+    check("step.loss_MDD", out["loss_MDD"].cpu().view(1), ref["loss_MDD"].view(1), 10 * tol)
+    assert torch.equal(out["predicted"].cpu(), ref["predicted"])
+    named = dict(m.named_parameters())
+    worst, nchk = 0.0, 0
+    for n, r in ref["grads"].items():
+        key = n
+        if ".trunk." in n:      # the trunk registers its tensors with '.' -> '__'
+            head, tail = n.split(".trunk.")
+            key = head + ".trunk." + tail.replace(".", "__")
+        g = named[key].grad
+        assert g is not None, key
+        g = g.cpu().double()
+        sc = r.abs().max().clamp_min(1e-12)
+        e = ((g - r).abs().max() / sc).item()
+        e32 = ((r32["grads"][n].double() - r).abs().max() / sc).item()
+        worst = max(worst, e); nchk += 1
+        assert e < max(5e-3, 10 * e32), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
+    print(f"[parity] full step: {nchk} gradient tensors, worst rel err vs fp64 oracle {worst:.3e}")
+    # Adam moved every parameter that has a gradient
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in m.named_parameters() if p.grad is not None)
+    assert moved == sum(1 for p in m.parameters() if p.grad is not None)

@@ -336,3 +336,20 @@ def test_mk_mmd(edrl, dev):
         check("mmd_ds", sg.grad.cpu(), sd.grad, 1e-3); check("mmd_dt", tg.grad.cpu(), td.grad, 1e-3)
     same = torch.randn(4, 32, generator=g).to(dev)
     assert edrl.MK_MMD(same, same.clone()).item() == 0.0, "MK_MMD(a,a) must be exactly 0 (reference golden)"
+
+
+def test_linear_odd_widths(edrl, dev):
+    """Classifier tail Linear(64, 2) (fusion_net.py:804-805): widths that are not multiples of 4 take the scalar loaders."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(12)
+    for rows, cin, cout in [(8, 64, 2), (5, 6, 3), (33, 130, 7)]:
+        x, w, b = torch.randn(rows, cin, generator=g), torch.randn(cout, cin, generator=g), torch.randn(cout, generator=g)
+        xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+        y = F.linear(xd, wd, bd)
+        gy = torch.randn(rows, cout, generator=g)
+        y.backward(gy.double())
+        xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+        yg = edrl.ops.linear(xg, wg, bg)
+        yg.backward(gy.to(dev))
+        check(f"lin{(rows, cin, cout)}", yg.cpu(), y, 2e-5)
+        check("dx", xg.grad.cpu(), xd.grad, 2e-5); check("dw", wg.grad.cpu(), wd.grad, 2e-5); check("db", bg.grad.cpu(), bd.grad, 2e-5)
