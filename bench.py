@@ -69,8 +69,13 @@ def main():
     def step():
         return edrl_amd.train_step(model, opt, data, y, grad_sync=sync.finish if sync else None)
 
+    if rank == 0:
+        print(f"[bench] {desc}: model ready, warm-up {a.warmup} step(s)", file=sys.stderr, flush=True)
     for _ in range(a.warmup):
         step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] timing {a.steps} step(s)", file=sys.stderr, flush=True)
     timer = None
     if not a.no_kernel_timing and rank == 0:
         timer = edrl_amd.ops.KernelTimer()
@@ -131,26 +136,29 @@ def main():
 
 
 def cpu_baseline(model, depth, HW, S):
-    """The oracle (torch-CPU restatement, `kind: port`) timed on this host on a bounded sample of the same
-    workload: ONE step at per-step batch 2 (the smallest batch train-mode BatchNorm admits) of the same
-    shapes/encoders."""
+    """The oracle (torch-CPU restatement, `kind: port`) timed on this host's cores on a BOUNDED sample of the
+    same workload: one full step (2 views fwd+bwd + MK_MMD + Adam) at batch 2 (the smallest batch train-mode
+    BatchNorm admits) with min(S, 16) OCT slices per sample, same encoders and image size.  The rate is scaled
+    to the workload's S slices by the conv+linear MAC ratio of one sample (stated in `sample`)."""
     import torch
     import edrl_amd
-    from oracle import step_oracle as SO
-    cores = os.cpu_count() or 1
+    from oracle import host_cores, step_oracle as SO
+    cores = min(host_cores(), 64)
     torch.set_num_threads(cores)
-    Bc = 2
+    Bc, Ss = 2, min(S, 16)
+    print(f"[bench] cpu_baseline: oracle step on {cores} host threads, batch {Bc}, {Ss} slices ...", file=sys.stderr, flush=True)
     orc = SO.OracleEDRL(model, dtype=torch.float32)
     orc.batch_size = Bc
-    data, y = edrl_amd.synthetic_batch(Bc, HW, HW, S, device="cpu", seed=99)
+    data, y = edrl_amd.synthetic_batch(Bc, HW, HW, Ss, device="cpu", seed=99)
     N2 = (HW // 32) ** 2
-    n1, n2 = SO.make_noise(1, Bc, N2, S), SO.make_noise(2, Bc, N2, S)
+    n1, n2 = SO.make_noise(1, Bc, N2, Ss), SO.make_noise(2, Bc, N2, Ss)
     t0 = time.perf_counter()
     orc.train_step(data, y, n1, n2, lr=1e-4, adam_state={})
     dt = time.perf_counter() - t0
-    return {"value": round(Bc / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 full step (2 views fwd+bwd + MK_MMD + Adam) at batch {Bc}, resnet{depth}, {HW}x{HW} + {S} slices, "
-                      f"torch-CPU fp32 oracle, {dt:.1f} s"}
+    ratio = (1.0 + S) / (1.0 + Ss)          # encoder passes per sample: 1 fundus + S slices (same trunk MACs/image +-2%)
+    return {"value": round(Bc / (dt * ratio), 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 full step at batch {Bc}, resnet{depth}, {HW}x{HW} fundus + {Ss} of {S} OCT slices, torch-CPU fp32 "
+                      f"oracle: {dt:.1f} s measured ({Bc / dt:.4f} images/s at {Ss} slices), scaled x1/{ratio:.2f} to {S} slices"}
 
 
 if __name__ == "__main__":

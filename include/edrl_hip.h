@@ -70,9 +70,9 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
                             float* running_mean, float* running_var, float momentum, float eps,
                             float* save_mean, float* save_rstd, float* scale, float* shift, float* workspace,
                             size_t workspace_bytes, hipStream_t stream);
-/* out = (relu?)(x*scale + shift [+ residual]) */
-int edrl_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
-                      long M, int C, long ld, int relu, hipStream_t stream);
+/* out = (relu?)((x - mean)*scale + shift [+ residual])   (scale = gamma*rstd, shift = beta) */
+int edrl_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift,
+                      const float* residual, float* out, long M, int C, long ld, int relu, hipStream_t stream);
 /* Backward of BN(+residual)(+ReLU).  dout = grad of the activated output, out = that output
  * (NULL when no ReLU); dx = grad of the raw input; dres (optional) [+]= masked dout.
  * workspace >= edrl_bn_workspace_bytes(M,C) + 2*C*4 bytes. */

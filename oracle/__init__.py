@@ -3,3 +3,28 @@
 Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this package;
 the product (the *_amd package) never does.  See oracle/edrl_oracle.py and oracle/resnet_oracle.py.
 """
+
+import os
+
+
+def host_cores():
+    """CPU cores this process may actually use (affinity mask capped by the cgroup quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)

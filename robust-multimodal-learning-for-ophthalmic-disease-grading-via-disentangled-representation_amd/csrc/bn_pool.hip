@@ -12,7 +12,10 @@
 
 #define BN_ROWS_PER_CHUNK 1024
 
-// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dout * (out > 0 if out given).
+// MODE 0: shifted moments (sum (x-K), sum (x-K)^2, K) with K = the chunk's first row: one pass, and no
+//         catastrophic cancellation when var << mean^2 (e.g. BatchNorm1d over 2 rows).
+// MODE 1: (sum g, sum g*xhat) with g = dout * (out > 0 if out given).
+// Partial layout: part[chunk][3][C].
 template <int MODE>
 __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ x, const float* __restrict__ dout,
                                                       const float* __restrict__ out,
@@ -35,12 +38,15 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
     if (MODE == 1) {
       mu = *reinterpret_cast<const f32x4*>(mean + c);
       rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    } else {
+      mu = *reinterpret_cast<const f32x4*>(x + row0 * ld + c);  // shift K
     }
     for (long r = row0 + rl; r < row1 && rl < RL; r += RL) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
       if (MODE == 0) {
-        s0 += xv;
-        s1 += xv * xv;
+        const f32x4 d = xv - mu;
+        s0 += d;
+        s1 += d * d;
       } else {
         f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
         if (out) {
@@ -64,9 +70,12 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
     for (int q = 0; q < RL; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) a[e] += sh[(q * CG + cg) * 8 + e];
-    float* p = part + (long)blockIdx.x * 2 * C;
+    float* p = part + (long)blockIdx.x * 3 * C;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { p[c + e] = a[e]; p[C + c + e] = a[4 + e]; }
+    for (int e = 0; e < 4; ++e) {
+      p[c + e] = a[e]; p[C + c + e] = a[4 + e];
+      if (MODE == 0) p[2 * C + c + e] = x[row0 * ld + c + e];
+    }
   }
 }
 
@@ -76,8 +85,8 @@ __device__ __forceinline__ void combine_partials(const float* part, int nchunks,
   double a0 = 0.0, a1 = 0.0;
   if (c < C)
     for (int k = q; k < nchunks; k += 4) {
-      a0 += (double)part[(long)k * 2 * C + c];
-      a1 += (double)part[(long)k * 2 * C + C + c];
+      a0 += (double)part[(long)k * 3 * C + c];
+      a1 += (double)part[(long)k * 3 * C + C + c];
     }
   const int t = threadIdx.x;
   sh[t] = a0; sh[256 + t] = a1;
@@ -97,11 +106,33 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ shift) {
   __shared__ double sh[512];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  double s0, s1;
-  combine_partials(part, nchunks, C, c, q, sh, s0, s1);
+  const int t = threadIdx.x, cc = t & 63;
+  // pass 1: mean = sum_c (n_c K_c + S1_c) / M
+  double a0 = 0.0;
+  if (c < C)
+    for (int k = q; k < nchunks; k += 4) {
+      const long r0 = (long)k * BN_ROWS_PER_CHUNK;
+      const double n = (double)((M - r0) < BN_ROWS_PER_CHUNK ? (M - r0) : BN_ROWS_PER_CHUNK);
+      a0 += n * (double)part[(long)k * 3 * C + 2 * C + c] + (double)part[(long)k * 3 * C + c];
+    }
+  sh[t] = a0;
+  __syncthreads();
+  const double mu = (sh[cc] + sh[64 + cc] + sh[128 + cc] + sh[192 + cc]) / (double)M;
+  __syncthreads();
+  // pass 2: M2 = sum_c [ S2_c - 2 (mu-K_c) S1_c + n_c (mu-K_c)^2 ]
+  double a1 = 0.0;
+  if (c < C)
+    for (int k = q; k < nchunks; k += 4) {
+      const long r0 = (long)k * BN_ROWS_PER_CHUNK;
+      const double n = (double)((M - r0) < BN_ROWS_PER_CHUNK ? (M - r0) : BN_ROWS_PER_CHUNK);
+      const double dk = mu - (double)part[(long)k * 3 * C + 2 * C + c];
+      a1 += (double)part[(long)k * 3 * C + C + c] - 2.0 * dk * (double)part[(long)k * 3 * C + c] + n * dk * dk;
+    }
+  sh[t] = a1;
+  __syncthreads();
+  const double m2 = sh[cc] + sh[64 + cc] + sh[128 + cc] + sh[192 + cc];
   if (q == 0 && c < C) {
-    const double mu = s0 / (double)M;
-    double var = s1 / (double)M - mu * mu;
+    double var = m2 / (double)M;
     if (var < 0.0) var = 0.0;
     const float rs = (float)(1.0 / sqrt(var + (double)eps));
     const float muf = (float)mu;
@@ -110,7 +141,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
     const float sc = gm * rs;
     scale[c] = sc;
-    shift[c] = bt - muf * sc;
+    shift[c] = bt;  // applied as (x - mean)*scale + shift: subtract first, no cancellation
     if (running_mean) {
       const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
@@ -135,8 +166,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
-// out = act(x*scale + shift + residual)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+// out = act((x-mean)*scale + shift + residual)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ residual,
                                                        float* __restrict__ out, long M, int C, long ld, int relu) {
@@ -146,9 +178,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const long r = i / C4;
     const int c = (int)(i - r * C4) * 4;
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c);
-    f32x4 v = xv * sc + sf;
+    f32x4 v = (xv - mu) * sc + sf;
     if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * ld + c);
     if (relu) {
 #pragma unroll
@@ -307,7 +340,7 @@ extern "C" {
 
 size_t edrl_bn_workspace_bytes(long M, int C) {
   const long chunks = (M + BN_ROWS_PER_CHUNK - 1) / BN_ROWS_PER_CHUNK;
-  return (size_t)chunks * 2 * C * sizeof(float);
+  return (size_t)chunks * 3 * C * sizeof(float);
 }
 
 // Train-mode batch statistics of x [M][C] (row stride ld) and the affine that applies them.
@@ -327,11 +360,11 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
   return 0;
 }
 
-int edrl_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
-                      long M, int C, long ld, int relu, hipStream_t st) {
+int edrl_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift,
+                      const float* residual, float* out, long M, int C, long ld, int relu, hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3) || (ld & 3)) return EDRL_EINVAL;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, scale, shift, residual, out,
-                     M, C, ld, relu);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, mean, scale, shift, residual,
+                     out, M, C, ld, relu);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

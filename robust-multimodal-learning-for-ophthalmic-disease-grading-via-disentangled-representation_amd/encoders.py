@@ -46,7 +46,7 @@ def _bn_fwd(raw, bn, relu, residual=None):
            P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(mean), P(rstd), P(scale), P(shift),
            P(ws), nbytes)
     out = torch.empty_like(raw)
-    L.call("edrl_bn_apply_f32", P(raw), P(scale), P(shift), P(residual), P(out), M, C, C, 1 if relu else 0)
+    L.call("edrl_bn_apply_f32", P(raw), P(mean), P(scale), P(shift), P(residual), P(out), M, C, C, 1 if relu else 0)
     return out, mean, rstd
 
 

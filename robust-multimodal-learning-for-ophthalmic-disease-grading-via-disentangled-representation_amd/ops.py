@@ -543,7 +543,7 @@ class BatchNorm1dTrainFn(torch.autograd.Function):
             L.call("edrl_bn_train_stats_f32", P(x), M, C, C, None, None, P(running_mean), P(running_var),
                    float(momentum), float(eps), P(mean), P(rstd), P(scale), P(shift), P(ws), nbytes)
         y = torch.empty_like(x)
-        L.call("edrl_bn_apply_f32", P(x), P(scale), P(shift), None, P(y), M, C, C, 0)
+        L.call("edrl_bn_apply_f32", P(x), P(mean), P(scale), P(shift), None, P(y), M, C, C, 0)
         ctx.save_for_backward(x, mean, rstd)
         return y
 

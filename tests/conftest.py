@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    from oracle import host_cores
+    torch.set_num_threads(min(host_cores(), 16))     # the CPU oracle must not oversubscribe the box's CPU share
 
 
 @pytest.fixture(scope="session")

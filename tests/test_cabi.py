@@ -31,7 +31,7 @@ def test_argument_errors_are_reported_without_a_gpu(edrl):
                                          None, 0, None) == -22   # C % 4 != 0
     ws = fn["edrl_conv2d_nhwc_wgrad_workspace_bytes"](4, 56, 56, 64, 64, 3, 3)
     assert ws > 0 and ws % (64 * 9 * 64 * 4) == 0
-    assert fn["edrl_bn_workspace_bytes"](3000, 256) == 3 * 2 * 256 * 4
+    assert fn["edrl_bn_workspace_bytes"](3000, 256) == 3 * 3 * 256 * 4
 
 
 def test_cpu_tensors_are_rejected_not_silently_computed(edrl):
