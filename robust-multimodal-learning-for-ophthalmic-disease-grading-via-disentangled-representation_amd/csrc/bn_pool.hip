@@ -41,21 +41,55 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
     } else {
       mu = *reinterpret_cast<const f32x4*>(x + row0 * ld + c);  // shift K
     }
-    for (long r = row0 + rl; r < row1 && rl < RL; r += RL) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
-      if (MODE == 0) {
-        const f32x4 d = xv - mu;
-        s0 += d;
-        s1 += d * d;
-      } else {
-        f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
-        if (out) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
+    // 4 rows per iteration: 4 (MODE 0) or 12 (MODE 1) independent 16-B loads in flight per lane
+    constexpr int U = 4;
+    long r = row0 + rl;
+    if (rl < RL) {
+      for (; r + (long)(U - 1) * RL < row1; r += (long)U * RL) {
+        f32x4 xv[U], gv[U], ov[U];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + (r + (long)u * RL) * ld + c);
+        if (MODE == 1) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) gv[u] = *reinterpret_cast<const f32x4*>(dout + (r + (long)u * RL) * ld + c);
+          if (out) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ov[u] = *reinterpret_cast<const f32x4*>(out + (r + (long)u * RL) * ld + c);
+          }
         }
-        s0 += g;
-        s1 += g * ((xv - mu) * rs);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (MODE == 0) {
+            const f32x4 d = xv[u] - mu;
+            s0 += d;
+            s1 += d * d;
+          } else {
+            f32x4 g = gv[u];
+            if (out) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) g[e] = ov[u][e] > 0.f ? g[e] : 0.f;
+            }
+            s0 += g;
+            s1 += g * ((xv[u] - mu) * rs);
+          }
+        }
+      }
+      for (; r < row1; r += RL) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+        if (MODE == 0) {
+          const f32x4 d = xv - mu;
+          s0 += d;
+          s1 += d * d;
+        } else {
+          f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
+          if (out) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+          }
+          s0 += g;
+          s1 += g * ((xv - mu) * rs);
+        }
       }
     }
   }
@@ -79,21 +113,29 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
   }
 }
 
-// Combine chunk partials in fp64. block = 64 channels x 4 chunk lanes.
+// Combine chunk partials in fp64. block = 16 channels x 16 chunk lanes.
+#define FIN_CH 16
+#define FIN_LANES 16
+__device__ __forceinline__ double fin_lane_sum(double v, double* sh) {
+  const int t = threadIdx.x, cc = t & (FIN_CH - 1);
+  __syncthreads();
+  sh[t] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < FIN_LANES; ++q) s += sh[q * FIN_CH + cc];
+  return s;
+}
 __device__ __forceinline__ void combine_partials(const float* part, int nchunks, int C, int c, int q,
                                                  double* sh, double& s0, double& s1) {
   double a0 = 0.0, a1 = 0.0;
   if (c < C)
-    for (int k = q; k < nchunks; k += 4) {
+    for (int k = q; k < nchunks; k += FIN_LANES) {
       a0 += (double)part[(long)k * 3 * C + c];
       a1 += (double)part[(long)k * 3 * C + C + c];
     }
-  const int t = threadIdx.x;
-  sh[t] = a0; sh[256 + t] = a1;
-  __syncthreads();
-  const int cc = t & 63;
-  s0 = sh[cc] + sh[64 + cc] + sh[128 + cc] + sh[192 + cc];
-  s1 = sh[256 + cc] + sh[320 + cc] + sh[384 + cc] + sh[448 + cc];
+  s0 = fin_lane_sum(a0, sh);
+  s1 = fin_lane_sum(a1, sh);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nchunks, int C,
@@ -104,33 +146,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, float* __restrict__ scale,
                                                           float* __restrict__ shift) {
-  __shared__ double sh[512];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  const int t = threadIdx.x, cc = t & 63;
+  __shared__ double sh[256];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
   // pass 1: mean = sum_c (n_c K_c + S1_c) / M
   double a0 = 0.0;
   if (c < C)
-    for (int k = q; k < nchunks; k += 4) {
+    for (int k = q; k < nchunks; k += FIN_LANES) {
       const long r0 = (long)k * BN_ROWS_PER_CHUNK;
       const double n = (double)((M - r0) < BN_ROWS_PER_CHUNK ? (M - r0) : BN_ROWS_PER_CHUNK);
       a0 += n * (double)part[(long)k * 3 * C + 2 * C + c] + (double)part[(long)k * 3 * C + c];
     }
-  sh[t] = a0;
-  __syncthreads();
-  const double mu = (sh[cc] + sh[64 + cc] + sh[128 + cc] + sh[192 + cc]) / (double)M;
-  __syncthreads();
+  const double mu = fin_lane_sum(a0, sh) / (double)M;
   // pass 2: M2 = sum_c [ S2_c - 2 (mu-K_c) S1_c + n_c (mu-K_c)^2 ]
   double a1 = 0.0;
   if (c < C)
-    for (int k = q; k < nchunks; k += 4) {
+    for (int k = q; k < nchunks; k += FIN_LANES) {
       const long r0 = (long)k * BN_ROWS_PER_CHUNK;
       const double n = (double)((M - r0) < BN_ROWS_PER_CHUNK ? (M - r0) : BN_ROWS_PER_CHUNK);
       const double dk = mu - (double)part[(long)k * 3 * C + 2 * C + c];
       a1 += (double)part[(long)k * 3 * C + C + c] - 2.0 * dk * (double)part[(long)k * 3 * C + c] + n * dk * dk;
     }
-  sh[t] = a1;
-  __syncthreads();
-  const double m2 = sh[cc] + sh[64 + cc] + sh[128 + cc] + sh[192 + cc];
+  const double m2 = fin_lane_sum(a1, sh);
   if (q == 0 && c < C) {
     double var = m2 / (double)M;
     if (var < 0.0) var = 0.0;
@@ -154,8 +190,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               long M, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ coef) {
-  __shared__ double sh[512];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  __shared__ double sh[256];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
   double s0, s1;
   combine_partials(part, nchunks, C, c, q, sh, s0, s1);
   if (q == 0 && c < C) {
@@ -354,7 +390,7 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
   hipLaunchKernelGGL(colstat_kernel<0>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, nullptr, nullptr,
                      nullptr, nullptr, M, C, ld, workspace);
   EDRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, 64)), dim3(256), 0, st, workspace, chunks, C, M, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M, gamma,
                      beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
   EDRL_LAUNCH_CHECK();
   return 0;
@@ -383,7 +419,7 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const float* x, const f
   hipLaunchKernelGGL(colstat_kernel<1>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout, out, save_mean,
                      save_rstd, M, C, ld, workspace);
   EDRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, 64)), dim3(256), 0, st, workspace, chunks, C, M,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M,
                      dgamma, dbeta, accumulate, coef);
   EDRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, out, x, save_mean,

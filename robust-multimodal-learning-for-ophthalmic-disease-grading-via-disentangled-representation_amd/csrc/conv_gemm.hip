@@ -35,6 +35,14 @@ struct GatherGeom {
   long ld_dst;      // destination pixel stride (elements)
   long ld_aux;      // pixel stride of `mul` / `addend` operands (elements)
   int flags;        // bit0 relu, bit1 accumulate into dst
+  // Sub-lattice ("parity class") view used by the strided data gradient: rows enumerate the
+  // destination pixels (h0 + i*step, w0 + j*step), i < OHs, j < OWs, and K runs over the taps
+  // (kh0 + a*kstep, kw0 + b*kstep), a < KHs, b < KWs — exactly the taps that hit that class, so no
+  // MFMA work is spent on masked taps.  The plain case is step = kstep = 1, h0 = w0 = kh0 = kw0 = 0.
+  int h0, w0, step, OHs, OWs;
+  int kh0, kw0, kstep, KHs, KWs;
+  int Kfull;        // KH*KW*SC: row stride of the weight matrix
+  int sshift;       // log2(stride) for DGRAD
 };
 
 #define GF_RELU 1
@@ -71,10 +79,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
   for (int i = 0; i < A_LD; ++i) {
     const long m = m0 + r0 + 32 * i;
     if (m < g.M) {
-      const int ohw = g.OH * g.OW;
+      const int ohw = g.OHs * g.OWs;
       const int n = (int)(m / ohw);
       const int rem = (int)(m - (long)n * ohw);
-      const int oh = rem / g.OW, ow = rem - oh * g.OW;
+      const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+      const int oh = g.h0 + ii * g.step, ow = g.w0 + jj * g.step;
       rbase[i] = n;
       if (DGRAD) { rh[i] = oh + g.pad; rw[i] = ow + g.pad; }
       else       { rh[i] = oh * g.stride - g.pad; rw[i] = ow * g.stride - g.pad; }
@@ -88,16 +97,21 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
     if (VEC) {
       const bool kvalid = k < g.Ktot;
       int tap = 0, c = 0, kh = 0, kw = 0;
-      if (kvalid) { tap = k / g.SC; c = k - tap * g.SC; kh = tap / g.KW; kw = tap - kh * g.KW; }
+      if (kvalid) {
+        tap = k / g.SC; c = k - tap * g.SC;
+        const int a = tap / g.KWs, b = tap - a * g.KWs;
+        kh = g.kh0 + a * g.kstep; kw = g.kw0 + b * g.kstep;
+      }
+      const long woff = (long)(kh * g.KW + kw) * g.SC + c;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         bool ok = kvalid && rbase[i] >= 0;
         int sh, sw;
         if (DGRAD) {
-          const int th = rh[i] - kh, tw = rw[i] - kw;
-          ok = ok && th >= 0 && tw >= 0 && (th % g.stride) == 0 && (tw % g.stride) == 0;
-          sh = th / g.stride; sw = tw / g.stride;
+          const int th = rh[i] - kh, tw = rw[i] - kw;   // divisible by the stride by construction of the class
+          ok = ok && th >= 0 && tw >= 0;
+          sh = th >> g.sshift; sw = tw >> g.sshift;
         } else { sh = rh[i] + kh; sw = rw[i] + kw; }
         ok = ok && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
         if (ok) {
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
       for (int i = 0; i < B_LD; ++i) {
         const int n = n0 + r0 + 32 * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kvalid && n < g.NC) v = *reinterpret_cast<const f32x4*>(wm + (long)n * g.Ktot + k);
+        if (kvalid && n < g.NC) v = *reinterpret_cast<const f32x4*>(wm + (long)n * g.Kfull + woff);
         b_st[i] = v;
       }
     } else {
@@ -121,15 +135,20 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
         const int ke = k + e;
         const bool kvalid = ke < g.Ktot;
         int tap = 0, c = 0, kh = 0, kw = 0;
-        if (kvalid) { tap = ke / g.SC; c = ke - tap * g.SC; kh = tap / g.KW; kw = tap - kh * g.KW; }
+        if (kvalid) {
+          tap = ke / g.SC; c = ke - tap * g.SC;
+          const int a = tap / g.KWs, b = tap - a * g.KWs;
+          kh = g.kh0 + a * g.kstep; kw = g.kw0 + b * g.kstep;
+        }
+        const long woff = (long)(kh * g.KW + kw) * g.SC + c;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
           bool ok = kvalid && rbase[i] >= 0;
           int sh, sw;
           if (DGRAD) {
             const int th = rh[i] - kh, tw = rw[i] - kw;
-            ok = ok && th >= 0 && tw >= 0 && (th % g.stride) == 0 && (tw % g.stride) == 0;
-            sh = th / g.stride; sw = tw / g.stride;
+            ok = ok && th >= 0 && tw >= 0;
+            sh = th >> g.sshift; sw = tw >> g.sshift;
           } else { sh = rh[i] + kh; sw = rw[i] + kw; }
           ok = ok && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
           float v = 0.f;
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
         for (int i = 0; i < B_LD; ++i) {
           const int n = n0 + r0 + 32 * i;
           float v = 0.f;
-          if (kvalid && n < g.NC) v = wm[(long)n * g.Ktot + ke];
+          if (kvalid && n < g.NC) v = wm[(long)n * g.Kfull + woff];
           b_st[i][e] = v;
         }
       }
@@ -211,16 +230,219 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
       for (int r = 0; r < 16; ++r) {
         const long m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < g.M) {
+          long pix = m;
+          if (DGRAD && g.step > 1) {   // sub-lattice rows -> destination pixel
+            const int ohw = g.OHs * g.OWs;
+            const int nn = (int)(m / ohw);
+            const int rem = (int)(m - (long)nn * ohw);
+            const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+            pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+          }
           float v = acc[i][j][r] + bv;
           if (relu) v = fmaxf(v, 0.f);
-          if (mul) v *= mul[m * g.ld_aux + n];
-          float* p = dst + m * g.ld_dst + n;
+          if (mul) v *= mul[pix * g.ld_aux + n];
+          float* p = dst + pix * g.ld_dst + n;
           if (accum) v += *p;
           *p = v;
         }
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vectorised fast path (SC % 4 == 0): same tiling and LDS image as above, but the operand staging is
+// branch-free (clamped address + select, so the 8 global loads of a K tile issue back to back) and is
+// issued in four pieces, one per 8-deep MFMA chunk, so that its address arithmetic and the loads sit in
+// the shadow of the 64-cycle fp32 MFMAs instead of in front of them.  The (tap, channel) decode of the
+// K index advances incrementally (no integer division in the loop).
+template <int BM, int BN, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
+    const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
+    const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_LD = (BM * BK / 4) / 256;
+  constexpr int B_LD = (BN * BK / 4) / 256;
+  static_assert(A_LD == 4, "four staging pieces per K tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int lid = edrl_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int k4 = (tid & 7) * 4;
+  const int r0 = tid >> 3;
+  int rn[A_LD], rh[A_LD], rw[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const long m = m0 + r0 + 32 * i;
+    if (m < g.M) {
+      const int ohw = g.OHs * g.OWs;
+      const int n = (int)(m / ohw);
+      const int rem = (int)(m - (long)n * ohw);
+      const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+      const int oh = g.h0 + ii * g.step, ow = g.w0 + jj * g.step;
+      rn[i] = n;
+      if (DGRAD) { rh[i] = oh + g.pad; rw[i] = ow + g.pad; }
+      else       { rh[i] = oh * g.stride - g.pad; rw[i] = ow * g.stride - g.pad; }
+    } else { rn[i] = -1; rh[i] = 0; rw[i] = 0; }
+  }
+  long wrow[B_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    wrow[i] = n < g.NC ? (long)n * g.Kfull : -1;
+  }
+
+  // incremental decode of k = kt*BK + k4 -> (ta, tb, c): tap (kh0 + ta*kstep, kw0 + tb*kstep), channel c
+  int c = k4, ta = 0, tb = 0, kk = k4;
+  while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
+  auto advance = [&]() {
+    c += BK; kk += BK;
+    while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
+  };
+
+  f32x4 a_st[A_LD], b_st[B_LD];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_piece = [&](int i) {
+    const bool kvalid = kk < g.Ktot;   // (a class of the strided dgrad may have no taps at all: Ktot == 0)
+    const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
+    {
+      int sh, sw;
+      bool ok = kvalid && rn[i] >= 0;
+      if (DGRAD) {
+        const int th = rh[i] - kh, tw = rw[i] - kw;
+        ok = ok && th >= 0 && tw >= 0;
+        sh = th >> g.sshift; sw = tw >> g.sshift;
+      } else { sh = rh[i] + kh; sw = rw[i] + kw; }
+      ok = ok && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+      const long pix = ((long)rn[i] * g.SH + sh) * g.SW + sw;
+      const long off = ok ? pix * g.ld_src + c : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + off);
+      a_st[i] = ok ? v : zero4;
+    }
+    if (i < B_LD) {
+      const bool ok = kvalid && wrow[i] >= 0;
+      const long off = ok ? wrow[i] + (long)(kh * g.KW + kw) * g.SC + c : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wm + off);
+      b_st[i] = ok ? v : zero4;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* a = As + buf * BM * LDK;
+    float* b = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDK + k4) = a_st[i];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDK + k4) = b_st[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = (g.Ktot + BK - 1) / BK;
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) load_piece(i);
+  store_tile(0);
+  __syncthreads();
+
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    advance();   // decode state of tile kt+1 (past the end: kvalid is false and the pieces load zeros)
+    const float* a = As + buf * BM * LDK + (wm0 + li) * LDK + 4 * lh;
+    const float* b = Bs + buf * BN * LDK + (wn0 + li) * LDK + 4 * lh;
+    // fragment registers are double buffered: chunk kc+1's LDS reads are issued ahead of chunk kc's 16 MFMAs
+    f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      const int cur = kc & 1, nxt = cur ^ 1;
+      if (kc + 1 < BK / 8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (kc + 1) * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + (kc + 1) * 8);
+      }
+      load_piece(kc);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+    }
+    store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const bool relu = g.flags & GF_RELU, accum = g.flags & GF_ACCUM;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + li;
+    if (n >= g.NC) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < g.M) {
+          long pix = m;
+          if (DGRAD && g.step > 1) {
+            const int ohw = g.OHs * g.OWs;
+            const int nn = (int)(m / ohw);
+            const int rem = (int)(m - (long)nn * ohw);
+            const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+            pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+          }
+          float v = acc[i][j][r] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (mul) v *= mul[pix * g.ld_aux + n];
+          float* p = dst + pix * g.ld_dst + n;
+          if (accum) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool DGRAD>
+static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
+                            const float* mul, const GatherGeom& g, hipStream_t st) {
+  const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
+  const long nblk = (long)tiles_m * tiles_n;
+  if (nblk <= 0) return 0;
+  if (nblk > 0x7fffffffL) return EDRL_EINVAL;
+  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, g, tiles_n);
+  EDRL_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int BM, int BN, bool DGRAD, bool VEC>
@@ -245,12 +467,12 @@ static int launch_gather(const float* src, const float* wm, float* dst, const fl
 template <bool DGRAD>
 static int dispatch_gather(const float* src, const float* wm, float* dst, const float* bias,
                            const float* mul, const GatherGeom& g, hipStream_t st) {
-  const bool vec = (g.SC % 4 == 0) && (g.ld_src % 4 == 0) && (g.Ktot % 4 == 0) &&
+  const bool vec = (g.SC % 4 == 0) && (g.ld_src % 4 == 0) && (g.Kfull % 4 == 0) &&
                    (((uintptr_t)src & 15) == 0) && (((uintptr_t)wm & 15) == 0);
   const bool narrow = g.NC <= 64;
   if (vec) {
-    if (narrow) return launch_gather<128, 64, DGRAD, true>(src, wm, dst, bias, mul, g, st);
-    return launch_gather<128, 128, DGRAD, true>(src, wm, dst, bias, mul, g, st);
+    if (narrow) return launch_gather_v2<128, 64, DGRAD>(src, wm, dst, bias, mul, g, st);
+    return launch_gather_v2<128, 128, DGRAD>(src, wm, dst, bias, mul, g, st);
   }
   if (narrow) return launch_gather<128, 64, DGRAD, false>(src, wm, dst, bias, mul, g, st);
   return launch_gather<128, 128, DGRAD, false>(src, wm, dst, bias, mul, g, st);
@@ -386,19 +608,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
       if (t + 1 < t_end) load_tile(t + 1);
       const float* a = As + buf * BK * LDA + wm0 + li;
       const float* b = Bs + buf * BK * LDB + wn0 + li;
+      // fragments for 4 k-steps are fetched ahead of the 4x(TM*TN) MFMAs that consume the previous 4
+      constexpr int KG = 4;
+      float af[2][KG][TM], bf[2][KG][TN];
 #pragma unroll
-      for (int ks = 0; ks < BK / 2; ++ks) {
-        const int k = 2 * ks + lh;
-        float af[TM], bf[TN];
+      for (int q = 0; q < KG; ++q) {
+        const int k = 2 * q + lh;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = a[k * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) af[0][q][i] = a[k * LDA + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = b[k * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) bf[0][q][j] = b[k * LDB + j * 32];
+      }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int kg = 0; kg < BK / 2 / KG; ++kg) {
+        const int cur = kg & 1, nxt = cur ^ 1;
+        if (kg + 1 < BK / 2 / KG) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int q = 0; q < KG; ++q) {
+            const int k = 2 * ((kg + 1) * KG + q) + lh;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[nxt][q][i] = a[k * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[nxt][q][j] = b[k * LDB + j * 32];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < KG; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][q][i], bf[cur][q][j], acc[i][j], 0, 0, 0);
       }
       if (t + 1 < t_end) store_tile(buf ^ 1);
       __syncthreads();
@@ -494,6 +734,8 @@ int edrl_conv2d_nhwc_fwd_f32(const float* x, const float* w, const float* bias, 
   g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
   g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
   g.ld_src = ld_x; g.ld_dst = ld_y; g.ld_aux = ld_aux; g.flags = flags;
+  g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
+  g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
   return dispatch_gather<false>(x, w, y, bias, mul, g, st);
 }
 
@@ -506,12 +748,32 @@ int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int 
       ld_dy < Co || ld_dx < Ci)
     return EDRL_EINVAL;
   if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
+  int sshift = 0;
+  while ((1 << sshift) < stride) ++sshift;
+  if ((1 << sshift) != stride) return EDRL_EINVAL;   // power-of-two strides only (ResNet: 1, 2)
   GatherGeom g;
-  g.M = (int)((long)N * Hi * Wi);
   g.OH = Hi; g.OW = Wi; g.NC = Ci; g.SH = Ho; g.SW = Wo; g.SC = Co;
-  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Co;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Kfull = KH * KW * Co;
   g.ld_src = ld_dy; g.ld_dst = ld_dx; g.ld_aux = 0; g.flags = flags;
-  return dispatch_gather<true>(dy, wt, dx, nullptr, nullptr, g, st);
+  g.step = stride; g.kstep = stride; g.sshift = sshift;
+  // one launch per parity class (ph, pw) = ((hi+pad) % s, (wi+pad) % s): only the taps kh = ph (mod s) reach it
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      g.h0 = ((ph - pad) % stride + stride) % stride;
+      g.w0 = ((pw - pad) % stride + stride) % stride;
+      g.OHs = g.h0 < Hi ? (Hi - g.h0 + stride - 1) / stride : 0;
+      g.OWs = g.w0 < Wi ? (Wi - g.w0 + stride - 1) / stride : 0;
+      if (g.OHs == 0 || g.OWs == 0) continue;
+      g.kh0 = ph; g.kw0 = pw;
+      g.KHs = ph < KH ? (KH - ph + stride - 1) / stride : 0;
+      g.KWs = pw < KW ? (KW - pw + stride - 1) / stride : 0;
+      g.Ktot = g.KHs * g.KWs * Co;
+      if (g.Ktot == 0 && (flags & GF_ACCUM)) continue;   // nothing reaches this class and dx keeps its value
+      g.M = (int)((long)N * g.OHs * g.OWs);
+      const int rc = dispatch_gather<true>(dy, wt, dx, nullptr, nullptr, g, st);
+      if (rc) return rc;
+    }
+  return 0;
 }
 
 size_t edrl_conv2d_nhwc_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW) {
