@@ -49,10 +49,17 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # EDRL_DIST_BACKEND=gloo + EDRL_DEVICE=0 rehearse the N>1 code path on a one-GPU box (every rank on cuda:0,
+    # host-staged collectives); the driver's real runs use one GPU per rank over RCCL ("nccl").
+    backend = os.environ.get("EDRL_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("EDRL_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B, depth, HW, S, desc = CONFIGS[a.config]
     if a.batch:
@@ -128,6 +135,16 @@ def main():
                 }
             res["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": round(v["tflops"], 3)} for k, v in ks.items()}
+        if "roofline" in res:
+            # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py);
+            # only quoted when those passes ran this very workload.
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_c1.json")))
+                if pm.get("workload") == desc and "conv_gather" in pm.get("kernels", {}):
+                    res["roofline"]["traffic"] = round(pm["kernels"]["conv_gather"]["hbm_bytes_per_launch"])
+                    res["roofline"]["traffic_source"] = "profiles/pmc_traffic_c1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            except (OSError, ValueError):
+                pass
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, depth, HW, S)
         print(json.dumps(res), flush=True)

@@ -20,6 +20,7 @@
 // Global->LDS is register staged and double buffered (one barrier per K tile):
 // tile t+1's loads are issued before tile t's MFMAs and written after them.
 #include "edrl_common.h"
+#include <stdlib.h>
 
 #define BK 32
 #define LDK (BK + 4)
@@ -256,18 +257,21 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
 // issued in four pieces, one per 8-deep MFMA chunk, so that its address arithmetic and the loads sit in
 // the shadow of the 64-cycle fp32 MFMAs instead of in front of them.  The (tap, channel) decode of the
 // K index advances incrementally (no integer division in the loop).
-template <int BM, int BN, bool DGRAD>
-__global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
+template <int BM, int BN, bool DGRAD, int BKT, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int A_LD = (BM * BK / 4) / 256;
-  constexpr int B_LD = (BN * BK / 4) / 256;
-  static_assert(A_LD == 4, "four staging pieces per K tile");
+  constexpr int LDKT = BKT + 4;
+  constexpr int KQ = BKT / 4;            // float4 columns per row of a K tile
+  constexpr int RPP = 256 / KQ;          // rows covered by one staging piece
+  constexpr int A_LD = BM / RPP;
+  constexpr int B_LD = BN / RPP;
+  static_assert(A_LD == BKT / 8, "one staging piece per 8-deep MFMA chunk");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + 2 * BM * LDK;
+  float* Bs = smem + 2 * BM * LDKT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -277,12 +281,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
 
-  const int k4 = (tid & 7) * 4;
-  const int r0 = tid >> 3;
+  const int k4 = (tid % KQ) * 4;
+  const int r0 = tid / KQ;
   int rn[A_LD], rh[A_LD], rw[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
-    const long m = m0 + r0 + 32 * i;
+    const long m = m0 + r0 + RPP * i;
     if (m < g.M) {
       const int ohw = g.OHs * g.OWs;
       const int n = (int)(m / ohw);
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
   long wrow[B_LD];
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) {
-    const int n = n0 + r0 + 32 * i;
+    const int n = n0 + r0 + RPP * i;
     wrow[i] = n < g.NC ? (long)n * g.Kfull : -1;
   }
 
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
   int c = k4, ta = 0, tb = 0, kk = k4;
   while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
   auto advance = [&]() {
-    c += BK; kk += BK;
+    c += BKT; kk += BKT;
     while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
   };
 
@@ -336,14 +340,14 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
     }
   };
   auto store_tile = [&](int buf) {
-    float* a = As + buf * BM * LDK;
-    float* b = Bs + buf * BN * LDK;
+    float* a = As + buf * BM * LDKT;
+    float* b = Bs + buf * BN * LDKT;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDK + k4) = a_st[i];
+      *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = a_st[i];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDK + k4) = b_st[i];
+      *reinterpret_cast<f32x4*>(b + (r0 + RPP * i) * LDKT + k4) = b_st[i];
   };
 
   f32x16 acc[TM][TN];
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = (g.Ktot + BK - 1) / BK;
+  const int KT = (g.Ktot + BKT - 1) / BKT;
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) load_piece(i);
   store_tile(0);
@@ -364,22 +368,22 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     advance();   // decode state of tile kt+1 (past the end: kvalid is false and the pieces load zeros)
-    const float* a = As + buf * BM * LDK + (wm0 + li) * LDK + 4 * lh;
-    const float* b = Bs + buf * BN * LDK + (wn0 + li) * LDK + 4 * lh;
+    const float* a = As + buf * BM * LDKT + (wm0 + li) * LDKT + 4 * lh;
+    const float* b = Bs + buf * BN * LDKT + (wn0 + li) * LDKT + 4 * lh;
     // fragment registers are double buffered: chunk kc+1's LDS reads are issued ahead of chunk kc's 16 MFMAs
     f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDKT);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDKT);
 #pragma unroll
-    for (int kc = 0; kc < BK / 8; ++kc) {
+    for (int kc = 0; kc < BKT / 8; ++kc) {
       const int cur = kc & 1, nxt = cur ^ 1;
-      if (kc + 1 < BK / 8) {
+      if (kc + 1 < BKT / 8) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (kc + 1) * 8);
+        for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDKT + (kc + 1) * 8);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + (kc + 1) * 8);
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDKT + (kc + 1) * 8);
       }
       load_piece(kc);
 #pragma unroll
@@ -426,15 +430,15 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_v2_kernel(
   }
 }
 
-template <int BM, int BN, bool DGRAD>
+template <int BM, int BN, bool DGRAD, int BKT, int OCC>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
                             const float* mul, const GatherGeom& g, hipStream_t st) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
   const long nblk = (long)tiles_m * tiles_n;
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
-  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD>;
+  const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -471,8 +475,15 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
                    (((uintptr_t)src & 15) == 0) && (((uintptr_t)wm & 15) == 0);
   const bool narrow = g.NC <= 64;
   if (vec) {
-    if (narrow) return launch_gather_v2<128, 64, DGRAD>(src, wm, dst, bias, mul, g, st);
-    return launch_gather_v2<128, 128, DGRAD>(src, wm, dst, bias, mul, g, st);
+    // K tile 16 -> 40 KiB of LDS and 128 VGPRs per workgroup: 3 workgroups (12 waves) per CU.  Measured on the
+    // ResNet-50 layer shapes (1024 images): +13 % over K tile 32 / 2 workgroups per CU (profiles/).
+    static const int variant = getenv("EDRL_GATHER_VARIANT") ? atoi(getenv("EDRL_GATHER_VARIANT")) : 1;
+    if (variant == 0) {   // K tile 32, 2 workgroups per CU (kept for A/B runs)
+      if (narrow) return launch_gather_v2<128, 64, DGRAD, 32, 2>(src, wm, dst, bias, mul, g, st);
+      return launch_gather_v2<128, 128, DGRAD, 32, 2>(src, wm, dst, bias, mul, g, st);
+    }
+    if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 3>(src, wm, dst, bias, mul, g, st);
+    return launch_gather_v2<128, 128, DGRAD, 16, 3>(src, wm, dst, bias, mul, g, st);
   }
   if (narrow) return launch_gather<128, 64, DGRAD, false>(src, wm, dst, bias, mul, g, st);
   return launch_gather<128, 128, DGRAD, false>(src, wm, dst, bias, mul, g, st);
@@ -490,24 +501,24 @@ struct WgradGeom {
   int tiles_per_split;
 };
 
-template <int BM, int BN, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
+template <int BM, int BN, bool VEC, int BKT, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int A_LD = (BM * BK / 4) / 256, B_LD = (BN * BK / 4) / 256;
+  constexpr int A_LD = (BM * BKT / 4) / 256, B_LD = (BN * BKT / 4) / 256;
   constexpr int AC4 = BM / 4, BC4 = BN / 4;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BK][LDA]
-  float* Bs = smem + 2 * BK * LDA;     // [2][BK][LDB]
+  float* Bs = smem + 2 * BKT * LDA;     // [2][BK][LDB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int co0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int split = blockIdx.z;
 
-  const long ptiles = (g.P + BK - 1) / BK;
+  const long ptiles = (g.P + BKT - 1) / BKT;
   const long t_begin = (long)split * g.tiles_per_split;
   long t_end = t_begin + g.tiles_per_split;
   if (t_end > ptiles) t_end = ptiles;
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
 
   f32x4 a_st[A_LD], b_st[B_LD];
   auto load_tile = [&](long t) {
-    const long p0 = t * BK;
+    const long p0 = t * BKT;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int row = (tid + 256 * i) / AC4;
@@ -576,8 +587,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
     }
   };
   auto store_tile = [&](int buf) {
-    float* a = As + buf * BK * LDA;
-    float* b = Bs + buf * BK * LDB;
+    float* a = As + buf * BKT * LDA;
+    float* b = Bs + buf * BKT * LDB;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int row = (tid + 256 * i) / AC4;
@@ -606,8 +617,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
     for (long t = t_begin; t < t_end; ++t) {
       const int buf = (int)((t - t_begin) & 1);
       if (t + 1 < t_end) load_tile(t + 1);
-      const float* a = As + buf * BK * LDA + wm0 + li;
-      const float* b = Bs + buf * BK * LDB + wn0 + li;
+      const float* a = As + buf * BKT * LDA + wm0 + li;
+      const float* b = Bs + buf * BKT * LDB + wn0 + li;
       // fragments for 4 k-steps are fetched ahead of the 4x(TM*TN) MFMAs that consume the previous 4
       constexpr int KG = 4;
       float af[2][KG][TM], bf[2][KG][TN];
@@ -620,9 +631,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(
         for (int j = 0; j < TN; ++j) bf[0][q][j] = b[k * LDB + j * 32];
       }
 #pragma unroll
-      for (int kg = 0; kg < BK / 2 / KG; ++kg) {
+      for (int kg = 0; kg < BKT / 2 / KG; ++kg) {
         const int cur = kg & 1, nxt = cur ^ 1;
-        if (kg + 1 < BK / 2 / KG) {
+        if (kg + 1 < BKT / 2 / KG) {
 #pragma unroll
           for (int q = 0; q < KG; ++q) {
             const int k = 2 * ((kg + 1) * KG + q) + lh;
@@ -670,11 +681,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   dw[i] = accumulate ? dw[i] + s : s;
 }
 
+#define WG_BK 16
+#define WG_OCC 3
 template <int BM, int BN, bool VEC>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st) {
-  const size_t lds = (size_t)2 * BK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC>;
+  const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, WG_OCC>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -690,9 +703,9 @@ static void wgrad_plan(long P, int Co, int Ktot, int* bm, int* bn, int* splits, 
   *bm = Co <= 64 ? 64 : 128;
   *bn = Ktot <= 64 ? 64 : 128;
   const long tiles = (long)edrl_cdiv(Co, *bm) * edrl_cdiv(Ktot, *bn);
-  const long ptiles = (P + BK - 1) / BK;
-  long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU in flight
-  long max_by_len = ptiles / 8; if (max_by_len < 1) max_by_len = 1;   // >= 8 K tiles per split
+  const long ptiles = (P + WG_BK - 1) / WG_BK;
+  long want = (1536 + tiles - 1) / tiles;          // ~6 blocks per CU in flight
+  long max_by_len = ptiles / 16; if (max_by_len < 1) max_by_len = 1;  // >= 16 K tiles per split
   long s = want < max_by_len ? want : max_by_len;
   if (s < 1) s = 1;
   if (s > 512) s = 512;

@@ -151,24 +151,28 @@ class _TrunkFn(torch.autograd.Function):
                 d3, g = bn_bwd(pre + ".bn3", dcur, rec["out"], rec["c3"], rec["sl"], want_dres=True)
             else:
                 d3, g = bn_bwd(pre + ".bn2", dcur, rec["out"], rec["c2"], rec["sl"], want_dres=True)
-            # identity / downsample branch -> dx
-            if blk["downsample"]:
-                dd, _ = bn_bwd(pre + ".downsample.1", g, None, rec["cd"], rec["sd"])
-                dx = conv_bwd(pre + ".downsample.0", dd, xin, s, 0)
-                del dd
-            else:
-                dx = g
-            del g
+            # Block-input gradient dx = (main path: conv1's dgrad, written first, covers every pixel)
+            #                         + (identity: g | downsample: its strided dgrad, accumulated afterwards so that
+            #                            only the parity class it reaches is touched — no zero fill, no re-read).
             if T.kind == "bottleneck":
                 da2 = conv_bwd(pre + ".conv3", d3, rec["a2"], 1, 0)
                 d2, _ = bn_bwd(pre + ".bn2", da2, rec["a2"], rec["c2"], rec["s2"])
                 da1 = conv_bwd(pre + ".conv2", d2, rec["a1"], s, 1)
                 d1, _ = bn_bwd(pre + ".bn1", da1, rec["a1"], rec["c1"], rec["s1"])
-                conv_bwd(pre + ".conv1", d1, xin, 1, 0, dx_out=dx, accumulate=True)
+                c1_stride, c1_pad = 1, 0
             else:
                 da1 = conv_bwd(pre + ".conv2", d3, rec["a1"], 1, 1)
                 d1, _ = bn_bwd(pre + ".bn1", da1, rec["a1"], rec["c1"], rec["s1"])
-                conv_bwd(pre + ".conv1", d1, xin, s, 1, dx_out=dx, accumulate=True)
+                c1_stride, c1_pad = s, 1
+            if blk["downsample"]:
+                dx = conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad)
+                dd, _ = bn_bwd(pre + ".downsample.1", g, None, rec["cd"], rec["sd"])
+                conv_bwd(pre + ".downsample.0", dd, xin, s, 0, dx_out=dx, accumulate=True)
+                del dd
+            else:
+                dx = g
+                conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad, dx_out=dx, accumulate=True)
+            del g
             dcur = dx
             del rec
         x, raw, a0, m0, r0, idx = saved.pop("stem")

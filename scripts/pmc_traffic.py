@@ -1,0 +1,33 @@
+"""Reduce two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of bench.py to per-launch HBM bytes of the conv kernels.
+Corrections per MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes
+of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B/lane stores.
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <workload description>"""
+import csv, glob, json, sys, collections
+
+def collect(d, counter):
+    f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))[-1]
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        fam = "conv_gather" if "conv_gather" in name else ("conv_wgrad" if "conv_wgrad" in name else name)
+        acc[fam][0] += 1
+        acc[fam][1] += float(r["Counter_Value"])
+    return acc
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+out = {"workload": sys.argv[4], "note": "bytes per launch; FETCH_SIZE KiB x1024 x2 (gfx950 half-count correction), WRITE_SIZE KiB x1024",
+       "kernels": {}}
+for fam in sorted(set(fetch) | set(write)):
+    nf, vf = fetch.get(fam, [0, 0.0]); nw, vw = write.get(fam, [0, 0.0])
+    n = max(nf, nw)
+    if n == 0:
+        continue
+    rd = vf * 1024 * 2 / max(nf, 1); wr = vw * 1024 / max(nw, 1)
+    out["kernels"][fam] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                           "hbm_bytes_per_launch": rd + wr}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for k in ("conv_gather", "conv_wgrad"):
+    if k in out["kernels"]:
+        print(k, out["kernels"][k])
