@@ -108,6 +108,7 @@ int edrl_bcast_axis1_f32(const float* in, float* out, long A, int L, int D, floa
 #define EDRL_EW_ADD_RELU 8
 #define EDRL_EW_SCALE_BY_PTR 9
 #define EDRL_EW_FILL 10
+#define EDRL_EW_LERP_BY_PTR 11
 int edrl_ew_f32(int op, long n, const float* a, const float* b, const float* c, float* out, float alpha,
                 float beta, hipStream_t stream);
 /* out = sum_i w[i] * *in[i]  (n <= 8) — loss mixers fusion_net.py:870-879,942-948, fusion_train.py:212.
@@ -175,6 +176,20 @@ int edrl_smooth_ce_fwd_f32(const float* pred, const long long* y, float* loss, i
 int edrl_smooth_ce_bwd_f32(const float* dloss, const float* pred, const long long* y, float* dpred, int B, int C,
                            float smoothing, hipStream_t stream);
 int edrl_argmax_rows_f32(const float* x, long long* out, int B, int C, hipStream_t stream);
+
+/* ---- eval branch of EPRL / eval-mode BatchNorm (fusion_net.py:152-218) ---- */
+int edrl_softmax_rows_f32(const float* x, float* y, int R, int C, hipStream_t stream);
+/* out[r] = scale * sum_d x[r][d]  — torch.mean(att, dim=2), torch.mean(z_norm, dim=2) (fusion_net.py:162-163). */
+int edrl_rowsum_f32(const float* x, float* out, long R, int D, long ld, float scale, hipStream_t stream);
+/* torch.max(combined, dim=1), confidence > threshold, fall back to the most confident sample
+ * (fusion_net.py:177-184); labels int64 [B], keep uint8 [B], count int32 [1]: bit-exact index ops. */
+int edrl_pseudo_label_f32(const float* comb, int B, int C, float threshold, long long* labels, unsigned char* keep,
+                          int* count, hipStream_t stream);
+/* EPRL.entropy_regularization (fusion_net.py:127-131) -> out[1]. */
+int edrl_entropy_rows_f32(const float* x, float* out, int R, int C, hipStream_t stream);
+/* eval-mode BatchNorm: scale = gamma/sqrt(running_var+eps), shift = beta; apply with edrl_bn_apply_f32(mean=running_mean). */
+int edrl_bn_eval_params_f32(const float* gamma, const float* beta, const float* running_var, float eps, float* scale,
+                            float* shift, int C, hipStream_t stream);
 
 /* ---- MK-MMD (mmd.hip; code/MMD.py:3-74) ------------------------------------------------- */
 int edrl_rowsq_f32(const float* x, float* sq, int n, int d, long ld, hipStream_t stream);

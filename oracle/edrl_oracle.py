@@ -121,6 +121,54 @@ def eprl_forward_train(p, pre, x, y, eps, mask1, mask2, batch_size):
     return mu_topk, sigma_topk, proxy_loss, z, {"att": att, "idx_pos": ip, "idx_neg": in_}
 
 
+def entropy_regularization(logits):
+    """fusion_net.py:127-131."""
+    pr = torch.softmax(logits, dim=1)
+    log_p = torch.log_softmax(logits, dim=1)
+    return (-torch.sum(pr * log_p, dim=1)).mean()
+
+
+def eprl_forward_eval(p, pre, x, eps):
+    """EPRL.forward, eval branch (fusion_net.py:133-218): dropout inactive, fixed-seed eps given explicitly."""
+    h = F.relu(F.linear(x, p[pre + "encoder.0.weight"], p[pre + "encoder.0.bias"]))
+    h = F.relu(F.linear(h, p[pre + "encoder.3.weight"], p[pre + "encoder.3.bias"]))
+    z = F.linear(h, p[pre + "encoder.6.weight"], p[pre + "encoder.6.bias"])
+    proxies = p[pre + "proxies"]
+    mu_proxy, sigma_proxy = proxies[:, :Z_DIM], F.softplus(proxies[:, Z_DIM:])
+    z_proxy = mu_proxy.unsqueeze(dim=1) + sigma_proxy.unsqueeze(dim=1) * eps
+    z_norm = F.normalize(z, dim=1)
+    z_proxy_norm = F.normalize(z_proxy)
+    threshold = 0.5                                                                              # :153
+    zpe = z_proxy_norm.unsqueeze(0).expand(1, -1, -1, -1)                                        # :155
+    att = torch.matmul(z_norm.unsqueeze(1), torch.transpose(zpe, 2, 3))                          # :157
+    att = att.permute(0, 2, 1, 3).mean(dim=1)                                                    # :158-159
+    att_mean = torch.mean(att, dim=2)                                                            # :162
+    z_mean = torch.mean(z_norm, dim=2)                                                           # :163
+    pl_att = torch.softmax(att_mean, dim=1)
+    pl_feat = torch.softmax(z_mean, dim=1)
+    mlp = "mlp_2d" if pl_feat.shape[1] == 144 else "mlp_3d"                                     # :168-171 (Q16)
+    pl_feat = F.relu(F.linear(F.relu(pl_feat), p[pre + mlp + ".1.weight"], p[pre + mlp + ".1.bias"]))
+    combined = p[pre + "alpha"] * pl_att + (1 - p[pre + "alpha"]) * pl_feat                     # :173
+    confidence, labels = torch.max(combined, dim=1)                                              # :177
+    mask = confidence > threshold
+    if mask.sum().item() == 0:
+        mask[confidence.argmax()] = True                                                         # :181-182
+    filtered = labels[mask]
+    proxies_dict = {"0": 0, "1": 1}
+    proxy_indices = torch.tensor([proxies_dict[str(int(v))] for v in filtered]).long()
+    m2 = torch.zeros(att.size(0), att.size(1), dtype=torch.bool)
+    m2[torch.arange(att.size(0)), proxy_indices] = True                                          # :190-191
+    att_positive = torch.masked_select(att, m2.unsqueeze(-1)).view(att.size(0), -1)
+    att_negative = torch.masked_select(att, ~m2.unsqueeze(-1)).view(att.size(0), -1)
+    tp, _ = torch.topk(att_positive, TOPK, dim=1)
+    tn, _ = torch.topk(att_negative, TOPK, dim=1)
+    proxy_loss = torch.mean(torch.exp(-torch.mean(tp, dim=1) + torch.mean(tn, dim=1)))          # :206
+    entropy_loss = entropy_regularization(combined)                                              # :208
+    B = x.shape[0]
+    return mu_proxy.repeat(B, 1, 1), sigma_proxy.repeat(B, 1, 1), proxy_loss, z, entropy_loss, \
+        {"labels": labels, "keep": mask, "combined": combined}
+
+
 def attention_model_forward(p, pre, x, y, z, embed=1024, heads=8):
     """AttentionModel.forward (fusion_net.py:569-578): nn.MultiheadAttention(1024, 8, batch_first) +
     residual + LayerNorm + FFN + residual + ReLU."""
@@ -150,6 +198,10 @@ def bt_loss_cross(z1n, z2n, common_dim, batch_size):
     return loss_c, on_diag_c, off_diag_c, loss_u, on_diag_u, off_diag_u
 
 
+def _bn1d_eval(x, state, name):
+    return F.batch_norm(x, state[name + ".running_mean"], state[name + ".running_var"], None, None, False, 0.1, 1e-5)
+
+
 def _bn1d_train(x, state, name, updates):
     """nn.BatchNorm1d(2048, affine=False) in train mode applied `updates` times to the same input
     (fusion_net.py:658 and :757-758: identical outputs, `updates` running-stat updates; quirk Q5)."""
@@ -160,7 +212,7 @@ def _bn1d_train(x, state, name, updates):
     return out
 
 
-def dilr_forward(p, state, pre, y1_2, y2_1, shared_features, funds_guided, octs_guided, batch_size):
+def dilr_forward(p, state, pre, y1_2, y2_1, shared_features, funds_guided, octs_guided, batch_size, training=True):
     """DILR.forward (fusion_net.py:714-768) with repair R2."""
     y1 = F.linear(y1_2, p[pre + "projector1.weight"], p[pre + "projector1.bias"])                # :716
     y2 = F.linear(y2_1, p[pre + "projector2.weight"], p[pre + "projector2.bias"])                # :717
@@ -180,12 +232,13 @@ def dilr_forward(p, state, pre, y1_2, y2_1, shared_features, funds_guided, octs_
     y1 = torch.cat((y1_common, y1_uni), dim=1)                                                   # :746
     y2 = torch.cat((y2_common, y2_uni), dim=1)
     common_dim_out = int(0.5 * y1.size(1))
-    z1 = _bn1d_train(y1, state, pre + "bn1", 1)                                                  # :658
-    z2 = _bn1d_train(y2, state, pre + "bn2", 1)
+    bn = (lambda t, n: _bn1d_train(t, state, n, 1)) if training else (lambda t, n: _bn1d_eval(t, state, n))
+    z1 = bn(y1, pre + "bn1")                                                                     # :658
+    z2 = bn(y2, pre + "bn2")
     loss_c, _, _, loss_u, _, _ = bt_loss_cross(z1, z2, common_dim_out, batch_size)
     loss12 = (loss_c + loss_u) / 2.0                                                             # :754
-    y1n = _bn1d_train(y1, state, pre + "bn1", 1)                                                 # :757
-    y2n = _bn1d_train(y2, state, pre + "bn2", 1)                                                 # :758
+    y1n = bn(y1, pre + "bn1")                                                                    # :757
+    y2n = bn(y2, pre + "bn2")                                                                    # :758
     combined = torch.cat((y1n[:, common_dim_out:], y1_common + y2_common, y2n[:, common_dim_out:]), dim=1)
     return combined, loss12
 
@@ -194,15 +247,20 @@ def medfusion_forward_tokens(p, state, x, x1, y, noise, batch_size, training=Tru
     """MedFusion.forward after the encoders (fusion_net.py:894-952), repairs R1+R2, train mode.
     noise = {"fundus": {eps, mask1, mask2}, "oct": {...}, "u_fundus", "u_oct"}."""
     nf, no = noise["fundus"], noise["oct"]
-    mu_f, sg_f, pl_f, z_f, aux_f = eprl_forward_train(p, "EPRL_fundus.", x, y, nf["eps"], nf["mask1"], nf["mask2"], batch_size)
-    mu_o, sg_o, pl_o, z_o, aux_o = eprl_forward_train(p, "EPRL_oct.", x1, y, no["eps"], no["mask1"], no["mask2"], batch_size)
+    if training:
+        mu_f, sg_f, pl_f, z_f, aux_f = eprl_forward_train(p, "EPRL_fundus.", x, y, nf["eps"], nf["mask1"], nf["mask2"], batch_size)
+        mu_o, sg_o, pl_o, z_o, aux_o = eprl_forward_train(p, "EPRL_oct.", x1, y, no["eps"], no["mask1"], no["mask2"], batch_size)
+    else:                                                                                        # :894-896
+        mu_f, sg_f, pl_f, z_f, _ent, aux_f = eprl_forward_eval(p, "EPRL_fundus.", x, nf["eps"])
+        mu_o, sg_o, pl_o, z_o, _ent, aux_o = eprl_forward_eval(p, "EPRL_oct.", x1, no["eps"])
     fundus_guided = mu_f + noise["u_fundus"] * sg_f                                              # :907
     oct_guided = mu_o + noise["u_oct"] * sg_o                                                    # :910
     poe_features = poe_forward(p["PoE.phi"], [mu_f, mu_o], [sg_f, sg_o])                         # :912
     poe_embed = torch.mean(poe_features, dim=1)                                                  # :913
     B = poe_embed.shape[0]
     global_fusion = F.relu(F.linear(F.relu(poe_embed.reshape(B, -1)), p["fc_fundus.1.weight"], p["fc_fundus.1.bias"]))
-    combine, loss_DILR = dilr_forward(p, state, "DILR.", x, x1, global_fusion, fundus_guided, oct_guided, batch_size)
+    combine, loss_DILR = dilr_forward(p, state, "DILR.", x, x1, global_fusion, fundus_guided, oct_guided, batch_size,
+                                      training)
     pred = F.linear(F.relu(F.linear(F.relu(combine), p["fc.1.weight"], p["fc.1.bias"])), p["fc.3.weight"], p["fc.3.bias"])
     pred = pred[:, :2]                                                                           # :930
     smoothing = 0.1
@@ -265,6 +323,23 @@ def make_head_params(seed, dtype=torch.float32):
             t = torch.randn(shape, generator=g) / math.sqrt(shape[1])
         p[name] = t.to(dtype)
     return p
+
+
+def make_eval_params(seed, dtype=torch.float32):
+    """Parameters only the eval branch uses (EPRL.alpha, mlp_2d/mlp_3d) + non-trivial BN running statistics."""
+    g = torch.Generator().manual_seed(seed)
+    p, st = {}, {}
+    for m in ("EPRL_fundus.", "EPRL_oct."):
+        p[m + "alpha"] = torch.tensor(0.37)
+        for name, n in (("mlp_2d", 144), ("mlp_3d", 216)):
+            p[m + name + ".1.weight"] = torch.randn(2, n, generator=g) * 0.5
+            p[m + name + ".1.bias"] = torch.tensor([0.8, 1.2])      # keeps every pseudo-label confident (> 0.5)
+    for n in ("DILR.bn1", "DILR.bn2"):
+        st[n + ".running_mean"] = 0.1 * torch.randn(2048, generator=g)
+        st[n + ".running_var"] = 0.5 + torch.rand(2048, generator=g)
+        st[n + ".num_batches_tracked"] = torch.tensor(7)
+    cast = lambda d: {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in d.items()}
+    return cast(p), cast(st)
 
 
 def make_bn_state(dtype=torch.float32):

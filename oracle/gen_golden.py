@@ -261,6 +261,33 @@ def gen_modules(ref):
     print("wrote head_modules.npz")
 
 
+def gen_eval(ref, tag, B, seed):
+    """Eval-mode forward (fusion_net.py:152-218, 870-874) at the reference-native token counts 144 / 216."""
+    N2, N3 = 144, 216
+    args = types.SimpleNamespace(mode="train&test", batch_size=B)
+    torch.manual_seed(0)
+    model = ref.MedFusion(2, 2, None, args)
+    params = O.make_head_params(seed)
+    ep, st = O.make_eval_params(seed + 5)
+    missing, unexpected = model.load_state_dict({**params, **ep, **st}, strict=False)
+    assert not unexpected, unexpected
+    model.eval()
+    x, x1, y, noise = O.make_head_inputs(seed + 1, B, N2, N3)
+    feed = RNGFeed()
+    with torch.no_grad(), feed:
+        feed.eps = [noise["fundus"]["eps"], noise["oct"]["eps"]]
+        feed.u = [noise["u_fundus"], noise["u_oct"]]
+        pred, loss, cf = model({0: x, 1: x1}, y, 0)
+    with torch.no_grad():
+        po, lo, co, aux = O.medfusion_forward_tokens({**params, **ep}, dict(st), x, x1, y, noise, B, training=False)
+    close(tag + " eval pred", po, pred); close(tag + " eval loss", lo.view(1), loss.view(1)); close(tag + " eval cf", co, cf)
+    assert bool(aux["sel_fundus"]["keep"].all()) and bool(aux["sel_oct"]["keep"].all())
+    np.savez_compressed(os.path.join(OUT, f"head_eval_{tag}.npz"), B=B, seed=seed, pred=pred.numpy(), loss=loss.item(),
+                        cf=cf.numpy(), labels_fundus=aux["sel_fundus"]["labels"].numpy(),
+                        labels_oct=aux["sel_oct"]["labels"].numpy())
+    print(f"wrote head_eval_{tag}.npz (loss {loss.item():.6f})")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -270,3 +297,4 @@ if __name__ == "__main__":
     gen_head(ref, ref_mmd, "tiny", 2, 9, 6, 21)
     gen_head(ref, ref_mmd, "refdims", 2, 144, 216, 31)
     gen_head(ref, ref_mmd, "b8", 8, 9, 6, 41)
+    gen_eval(ref, "b4", 4, 51)

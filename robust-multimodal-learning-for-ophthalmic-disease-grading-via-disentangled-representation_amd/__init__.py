@@ -11,9 +11,9 @@ from . import _lib, ops
 from .mmd import MK_MMD
 from .medfusion import MedFusion, EPRL, PoE, DILR, AttentionModel, off_diagonal
 from .encoders import ResNetTrunk, FundusEncoder, OCTSliceEncoder
-from .train import train_step, train, synthetic_batch
+from .train import train_step, train, val, synthetic_batch
 from .dist import GradSync, broadcast_parameters
 
 __all__ = ["MedFusion", "EPRL", "PoE", "DILR", "AttentionModel", "off_diagonal", "MK_MMD", "ResNetTrunk",
-           "FundusEncoder", "OCTSliceEncoder", "train_step", "train", "synthetic_batch", "ops", "GradSync",
+           "FundusEncoder", "OCTSliceEncoder", "train_step", "train", "val", "synthetic_batch", "ops", "GradSync",
            "broadcast_parameters"]

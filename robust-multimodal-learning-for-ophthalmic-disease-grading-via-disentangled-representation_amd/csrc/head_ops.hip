@@ -32,7 +32,8 @@ enum {
   EW_MASKED_BWD = 7,  // out = a * b * (c > 0)   (dy * dropout_mask * relu-mask of the output)
   EW_ADD_RELU = 8,    // out = max(a+b,0)
   EW_SCALE_BY_PTR = 9,// out = a * (*s) * alpha   (s = device scalar in b)
-  EW_FILL = 10        // out = alpha
+  EW_FILL = 10,       // out = alpha
+  EW_LERP_BY_PTR = 11 // out = s*a + (1-s)*b, s = c[0] (device scalar)   (fusion_net.py:173)
 };
 
 __global__ __launch_bounds__(256) void ew_kernel(int op, long n, const float* __restrict__ a,
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void ew_kernel(int op, long n, const float* __
       case EW_ADD_RELU: v = fmaxf(a[i] + b[i], 0.f); break;
       case EW_SCALE_BY_PTR: v = a[i] * b[0] * alpha; break;
       case EW_FILL: v = alpha; break;
+      case EW_LERP_BY_PTR: v = c[0] * a[i] + (1.f - c[0]) * b[i]; break;
     }
     out[i] = v;
   }
@@ -577,11 +579,120 @@ __global__ void argmax_rows_kernel(const float* __restrict__ x, long long* __res
   }
 }
 
+
+// ------------------------------------------------------------------ eval-branch helpers (fusion_net.py:152-218)
+// y[r][:] = softmax(x[r][:]); one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = x + (long)row * C;
+  float m = -INFINITY;
+  for (int i = lane; i < C; i += 64) m = fmaxf(m, p[i]);
+  m = edrl_wave_max(m);
+  float s = 0.f;
+  for (int i = lane; i < C; i += 64) s += expf(p[i] - m);
+  s = edrl_wave_sum(s);
+  for (int i = lane; i < C; i += 64) y[(long)row * C + i] = expf(p[i] - m) / s;
+}
+// out[r] = scale * sum_d x[r][d]; one wave per row
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, float* __restrict__ out, long R, int D,
+                                                     long ld, float scale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += x[row * ld + i];
+  s = edrl_wave_sum(s);
+  if (lane == 0) out[row] = s * scale;
+}
+// Pseudo-label selection (fusion_net.py:177-184): confidence/label = max/argmax over classes (first maximum),
+// keep = confidence > threshold, and if nothing is kept the most confident sample is. count[0] = #kept.
+__global__ void pseudo_label_kernel(const float* __restrict__ comb, int B, int C, float thr, long long* __restrict__ labels,
+                                    unsigned char* __restrict__ keep, int* __restrict__ count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0, best_b = 0;
+  float best_c = -INFINITY;
+  for (int b = 0; b < B; ++b) {
+    float cf = comb[(long)b * C];
+    int lb = 0;
+    for (int k = 1; k < C; ++k) { const float v = comb[(long)b * C + k]; if (v > cf) { cf = v; lb = k; } }
+    labels[b] = lb;
+    keep[b] = cf > thr ? 1 : 0;
+    n += keep[b];
+    if (cf > best_c) { best_c = cf; best_b = b; }
+  }
+  if (n == 0) { keep[best_b] = 1; n = 1; }
+  count[0] = n;
+}
+// mean_r ( - sum_k softmax(x_r)_k * log_softmax(x_r)_k )    (EPRL.entropy_regularization, fusion_net.py:127-131)
+__global__ __launch_bounds__(256) void entropy_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float* p = x + (long)r * C;
+    float m = -INFINITY;
+    for (int k = 0; k < C; ++k) m = fmaxf(m, p[k]);
+    float z = 0.f;
+    for (int k = 0; k < C; ++k) z += expf(p[k] - m);
+    const float lz = logf(z) + m;
+    float e = 0.f;
+    for (int k = 0; k < C; ++k) e -= expf(p[k] - lz) * (p[k] - lz);
+    s += e;
+  }
+  s = edrl_block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s / (float)R;
+}
+// eval-mode BatchNorm as the (mean, scale, shift) triple of edrl_bn_apply_f32: scale = gamma / sqrt(var + eps)
+__global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rv, float eps, float* __restrict__ scale,
+                                      float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  scale[c] = (gamma ? gamma[c] : 1.f) / sqrtf(rv[c] + eps);
+  shift[c] = beta ? beta[c] : 0.f;
+}
+
 extern "C" {
+
+int edrl_softmax_rows_f32(const float* x, float* y, int R, int C, hipStream_t st) {
+  if (R <= 0 || C <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(edrl_cdiv(R, 4)), dim3(256), 0, st, x, y, R, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_rowsum_f32(const float* x, float* out, long R, int D, long ld, float scale, hipStream_t st) {
+  if (R <= 0 || D <= 0 || ld < D) return EDRL_EINVAL;
+  hipLaunchKernelGGL(rowsum_kernel, dim3(edrl_cdiv(R, 4)), dim3(256), 0, st, x, out, R, D, ld, scale);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_pseudo_label_f32(const float* comb, int B, int C, float threshold, long long* labels, unsigned char* keep,
+                          int* count, hipStream_t st) {
+  if (B <= 0 || C <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(pseudo_label_kernel, dim3(1), dim3(64), 0, st, comb, B, C, threshold, labels, keep, count);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_entropy_rows_f32(const float* x, float* out, int R, int C, hipStream_t st) {
+  if (R <= 0 || C <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(entropy_rows_kernel, dim3(1), dim3(256), 0, st, x, out, R, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_bn_eval_params_f32(const float* gamma, const float* beta, const float* running_var, float eps, float* scale,
+                            float* shift, int C, hipStream_t st) {
+  if (C <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3(edrl_cdiv(C, 256)), dim3(256), 0, st, gamma, beta, running_var, eps,
+                     scale, shift, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
 
 int edrl_ew_f32(int op, long n, const float* a, const float* b, const float* c, float* out, float alpha,
                 float beta, hipStream_t st) {
-  if (n < 0 || op < 0 || op > EW_FILL) return EDRL_EINVAL;
+  if (n < 0 || op < 0 || op > EW_LERP_BY_PTR) return EDRL_EINVAL;
   if (n == 0) return 0;
   hipLaunchKernelGGL(ew_kernel, dim3(ew_grid(n)), dim3(256), 0, st, op, n, a, b, c, out, alpha, beta);
   EDRL_LAUNCH_CHECK();

@@ -258,9 +258,40 @@ class ResNetTrunk(nn.Module):
 
     def forward(self, x_nhwc):
         if not self.training:
-            raise NotImplementedError("eval-mode (running-stat) encoder forward is a SURVEY §8(f) 'next' row")
+            return self.forward_eval(x_nhwc)
         params = [self.get(n) for n in self.param_names]
         return _TrunkFn.apply(self, x_nhwc, *params)
+
+    @torch.no_grad()
+    def forward_eval(self, x):
+        """Inference forward (running-stat BatchNorm, nothing saved): same HIP conv / BN-apply / pooling kernels."""
+        x = ops._chk(x, "encoder input")
+
+        def bn(name, raw, relu, residual=None):
+            return ops.batchnorm_eval(raw, self.get(name + ".running_mean"), self.get(name + ".running_var"),
+                                      self.get(name + ".weight"), self.get(name + ".bias"), 1e-5, relu, residual)
+
+        def conv(name, inp, stride, pad):
+            return ops.conv2d_fwd(inp, self.get(name + ".weight"), stride=stride, pad=pad)
+
+        a0 = bn("bn1", conv("conv1", x, 2, 3), True)
+        N, H, W, C = a0.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        cur = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        L.call("edrl_maxpool3x3s2_fwd_f32", P(a0), P(cur), P(idx), N, H, W, C)
+        for blk in self.blocks:
+            pre, s = blk["name"], blk["stride"]
+            if self.kind == "bottleneck":
+                o = bn(pre + ".bn1", conv(pre + ".conv1", cur, 1, 0), True)
+                o = bn(pre + ".bn2", conv(pre + ".conv2", o, s, 1), True)
+                last, last_bn = conv(pre + ".conv3", o, 1, 0), pre + ".bn3"
+            else:
+                o = bn(pre + ".bn1", conv(pre + ".conv1", cur, s, 1), True)
+                last, last_bn = conv(pre + ".conv2", o, 1, 1), pre + ".bn2"
+            idn = bn(pre + ".downsample.1", conv(pre + ".downsample.0", cur, s, 0), False) if blk["downsample"] else cur
+            cur = bn(last_bn, last, True, residual=idn)
+        return cur
 
 
 class FundusEncoder(nn.Module):

@@ -50,10 +50,14 @@ class PoE(nn.Module):
 
     def forward(self, mu_list, var_list, eps=1e-8):
         out = ops.poe2(mu_list[0], var_list[0], mu_list[1], var_list[1], self.phi, eps)
-        if self.rng == "reference" and self.training:
-            # the reference draws (and discards) eps here, advancing the global generator (fusion_net.py:44-46)
-            torch.normal(torch.zeros(out.shape[0], self.sample_num, out.shape[1]),
-                         torch.ones(out.shape[0], self.sample_num, out.shape[1]))
+        if self.rng == "reference":
+            # the reference draws (and discards) eps here (fusion_net.py:44-46): in train mode it advances the global
+            # generator, in eval mode it RESEEDS it (generator=torch.manual_seed(seed), :59-60, quirk Q8)
+            shp = (out.shape[0], self.sample_num, out.shape[1])
+            if self.training:
+                torch.normal(torch.zeros(*shp), torch.ones(*shp))
+            else:
+                torch.normal(torch.zeros(*shp), torch.ones(*shp), generator=torch.manual_seed(self.seed))
         return out.unsqueeze(1)  # [B, 1, 2, 256]  (mu + var; sampling is commented out at :48)
 
 
@@ -94,9 +98,53 @@ class EPRL(nn.Module):
         h = ops.linear(h, e[3].weight, e[3].bias, relu=True, mask=m2)
         return ops.linear(h, e[6].weight, e[6].bias)
 
+    def _eval_eps(self, device):
+        """Eval noise: `torch.normal(..., generator=torch.manual_seed(seed))` (fusion_net.py:109-110) — quirk Q8:
+        rng="reference" reproduces it literally (it RESEEDS the global CPU generator); rng="device" draws the same
+        fixed-seed noise from a private device generator and leaves the global state alone."""
+        C, S, zd = self.num_classes, self.sample_num, self.z_dim
+        if self.rng == "reference":
+            return torch.normal(torch.zeros(C, S, zd), torch.ones(C, S, zd), generator=torch.manual_seed(self.seed)).to(device)
+        g = torch.Generator(device=device).manual_seed(self.seed)
+        return torch.randn(C, S, zd, device=device, generator=g)
+
+    @torch.no_grad()
+    def forward_eval(self, x, noise=None):
+        """Eval branch (fusion_net.py:152-218): pseudo-labels from attention + token statistics, forward only."""
+        B, N, _ = x.shape
+        C, S, zd = self.num_classes, self.sample_num, self.z_dim
+        z = self.encoder_result(x, None)
+        mu_proxy, sigma_proxy = self.encoder_proxies()
+        eps = noise["eps"] if noise and "eps" in noise else self._eval_eps(x.device)
+        z_proxy = ops.affine_bcast(mu_proxy, sigma_proxy, eps)
+        z_norm = ops.l2norm_axis1(z)
+        z_proxy_norm = ops.l2norm_axis1(z_proxy)
+        zbar = ops.mean_axis1(z_norm)
+        att = ops.linear(zbar, z_proxy_norm.view(C * S, zd)).view(B, C, S)                 # :157-159
+        att_mean = ops.rowmean(att.view(B * C, S)).view(B, C)                              # :162
+        z_mean = ops.rowmean(z_norm.view(B * N, zd)).view(B, N)                            # :163
+        pl_att = ops.softmax_rows(att_mean)                                                # :166
+        pl_feat = ops.softmax_rows(z_mean)                                                 # :167
+        mlp = self.mlp_2d if N == 144 else self.mlp_3d                                     # :168-171 (Q16)
+        pl_feat = ops.linear(ops.relu(pl_feat), mlp[1].weight, mlp[1].bias, relu=True)
+        combined = ops.ew(ops.EW_LERP_BY_PTR, pl_att, pl_feat, self.alpha.detach().view(1))    # :173
+        labels, keep, count = ops.pseudo_label(combined, 0.5)                              # :177-184
+        k = int(count.item())
+        if k == B:
+            proxy_labels = labels
+        elif k == 1:                                    # the single kept label broadcasts over arange(B) (:191)
+            proxy_labels = labels[keep.bool()].expand(B).contiguous()
+        else:
+            raise IndexError(f"shape mismatch: indexing tensors could not be broadcast together with shapes [{B}], [{k}]")
+        proxy_loss, _ = ops.topk_margin(att, proxy_labels, self.self_topk)                 # :190-206
+        entropy_loss = ops.entropy_rows(combined)                                          # :208
+        mu_topk = ops.repeat_axis1(mu_proxy.reshape(1, C * zd), B).view(B, C, zd)
+        sigma_topk = ops.repeat_axis1(sigma_proxy.reshape(1, C * zd), B).view(B, C, zd)
+        return mu_topk, sigma_topk, proxy_loss, z, entropy_loss
+
     def forward(self, x, y=None, noise=None):
         if not self.training:
-            raise NotImplementedError("EPRL eval branch (fusion_net.py:152-218) is a SURVEY §8(f) 'next' row")
+            return self.forward_eval(x, noise)
         B, N, _ = x.shape
         if B != self.batch_size:  # quirk Q9: expand(self.batch_size) at fusion_net.py:221
             raise RuntimeError(f"The expanded size of the tensor ({self.batch_size}) must match the existing size "
@@ -161,7 +209,7 @@ class DILR(nn.Module):
 
     def _bn(self, bn, x, updates):
         if not self.training:
-            raise NotImplementedError("eval-mode DILR is a SURVEY §8(f) 'next' row")
+            return ops.batchnorm_eval(x, bn.running_mean, bn.running_var, None, None, bn.eps)
         bn.num_batches_tracked += updates
         return ops.batchnorm1d_train(x, bn.running_mean, bn.running_var, bn.momentum, bn.eps, updates)
 
@@ -255,8 +303,12 @@ class MedFusion(nn.Module):
     def forward_tokens(self, x, x1, y, noise=None):
         """Everything after the encoders (fusion_net.py:894-952). x [B,N2,1024], x1 [B,N3,768]."""
         noise = noise or {}
-        mu_f, sg_f, pl_f, z_f = self.EPRL_fundus(x, y=y, noise=noise.get("fundus"))
-        mu_o, sg_o, pl_o, z_o = self.EPRL_oct(x1, y=y, noise=noise.get("oct"))
+        if self.training:
+            mu_f, sg_f, pl_f, z_f = self.EPRL_fundus(x, y=y, noise=noise.get("fundus"))
+            mu_o, sg_o, pl_o, z_o = self.EPRL_oct(x1, y=y, noise=noise.get("oct"))
+        else:   # fusion_net.py:894-896: the entropy term is computed but not added (:872-873)
+            mu_f, sg_f, pl_f, z_f, _entropy = self.EPRL_fundus(x, y=y, noise=noise.get("fundus"))
+            mu_o, sg_o, pl_o, z_o, _entropy = self.EPRL_oct(x1, y=y, noise=noise.get("oct"))
         B, C, zd = mu_f.shape
         dev = x.device
 

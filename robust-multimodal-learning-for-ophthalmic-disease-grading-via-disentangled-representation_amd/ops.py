@@ -12,7 +12,7 @@ from . import _lib as L
 P = L.ptr
 
 EW_RELU, EW_RELU_BWD, EW_AXPBY, EW_MUL, EW_SCALE, EW_SOFTPLUS, EW_SOFTPLUS_BWD, EW_MASKED_BWD, \
-    EW_ADD_RELU, EW_SCALE_BY_PTR, EW_FILL = range(11)
+    EW_ADD_RELU, EW_SCALE_BY_PTR, EW_FILL, EW_LERP_BY_PTR = range(12)
 FLAG_RELU, FLAG_ACCUM = 1, 2
 
 
@@ -710,3 +710,49 @@ class MkMmdFn(torch.autograd.Function):
 
 def mk_mmd(source, target, kernel_mul=2.0, kernel_num=5):
     return MkMmdFn.apply(source, target, kernel_mul, kernel_num)
+
+
+# ------------------------------------------------------------------ forward-only helpers of the eval path (no autograd)
+def softmax_rows(x2):
+    x2 = _chk(x2.detach(), "softmax.x", False).contiguous()
+    y = torch.empty_like(x2)
+    L.call("edrl_softmax_rows_f32", P(x2), P(y), x2.shape[0], x2.shape[1])
+    return y
+
+
+def rowmean(x2):
+    """[R, D] -> [R] mean over the last axis."""
+    x2 = _chk(x2.detach(), "rowmean.x", False).contiguous()
+    out = torch.empty((x2.shape[0],), device=x2.device, dtype=torch.float32)
+    L.call("edrl_rowsum_f32", P(x2), P(out), x2.shape[0], x2.shape[1], x2.shape[1], 1.0 / x2.shape[1])
+    return out
+
+
+def pseudo_label(combined, threshold):
+    combined = _chk(combined.detach(), "pseudo.x", False).contiguous()
+    B, C = combined.shape
+    labels = torch.empty((B,), device=combined.device, dtype=torch.int64)
+    keep = torch.empty((B,), device=combined.device, dtype=torch.uint8)
+    count = torch.zeros((1,), device=combined.device, dtype=torch.int32)
+    L.call("edrl_pseudo_label_f32", P(combined), B, C, float(threshold), P(labels), P(keep), P(count))
+    return labels, keep, count
+
+
+def entropy_rows(x2):
+    x2 = _chk(x2.detach(), "entropy.x", False).contiguous()
+    out = torch.empty((1,), device=x2.device, dtype=torch.float32)
+    L.call("edrl_entropy_rows_f32", P(x2), P(out), x2.shape[0], x2.shape[1])
+    return out.view(())
+
+
+def batchnorm_eval(x, running_mean, running_var, gamma=None, beta=None, eps=1e-5, relu=False, residual=None):
+    """Eval-mode BatchNorm (running statistics) on [..., C] rows, optional residual add and ReLU."""
+    x = _chk(x.detach(), "bn_eval.x", False).contiguous()
+    C = x.shape[-1]
+    M = x.numel() // C
+    scale = torch.empty((C,), device=x.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    L.call("edrl_bn_eval_params_f32", P(gamma), P(beta), P(running_var), float(eps), P(scale), P(shift), C)
+    y = torch.empty_like(x)
+    L.call("edrl_bn_apply_f32", P(x), P(running_mean), P(scale), P(shift), P(residual), P(y), M, C, C, 1 if relu else 0)
+    return y

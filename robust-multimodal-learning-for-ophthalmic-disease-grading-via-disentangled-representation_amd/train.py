@@ -60,3 +60,24 @@ def train(epoch, train_loader, model, optimizer, log_every=0):
     if hasattr(model, "raise_on_bad_labels"):
         model.raise_on_bad_labels()
     return {"loss": (loss_sum / max(n_batches, 1)).item(), "acc": correct.item() / max(n_seen, 1)}
+
+
+@torch.no_grad()
+def val(current_epoch, val_loader, model, best_acc, save_path=None):
+    """fusion_train.val() (fusion_train.py:267-334): eval-mode forward on the low-noise view only (:277),
+    accuracy / mean loss, and the best-accuracy checkpoint `{'epoch', 'state_dict'}` (:324-332)."""
+    model.eval()
+    dev = next(model.parameters()).device
+    correct = torch.zeros((), device=dev, dtype=torch.int64)
+    loss_sum = torch.zeros((), device=dev)
+    n_batches, n_seen = 0, 0
+    for data, target in val_loader:
+        pred, loss, _ = model(data[0], target, current_epoch)
+        correct += (ops.argmax_rows(pred) == target).sum()
+        loss_sum += loss
+        n_batches += 1
+        n_seen += target.shape[0]
+    acc = correct.item() / max(n_seen, 1)
+    if acc > best_acc and save_path is not None:
+        torch.save({"epoch": current_epoch, "state_dict": model.state_dict()}, save_path)
+    return {"loss": (loss_sum / max(n_batches, 1)).item(), "acc": acc, "best_acc": max(acc, best_acc)}

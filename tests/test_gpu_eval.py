@@ -1,0 +1,92 @@
+"""GPU parity of the eval path: EPRL eval branch + eval-mode BatchNorm + val()."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import edrl_oracle as O
+from util import check
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def to_dev(o, dev):
+    if isinstance(o, dict):
+        return {k: to_dev(v, dev) for k, v in o.items()}
+    return o.to(dev)
+
+
+def test_eval_forward_vs_reference_fixture(edrl, dev):
+    z = np.load(os.path.join(GOLD, "head_eval_b4.npz"))
+    B, seed = int(z["B"]), int(z["seed"])
+    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=18)
+    torch.manual_seed(0)
+    m = edrl.MedFusion(2, 2, None, args)
+    ep, st = O.make_eval_params(seed + 5)
+    missing, unexpected = m.load_state_dict({**O.make_head_params(seed), **ep, **st}, strict=False)
+    assert not unexpected
+    m = m.to(dev).eval()
+    x, x1, y, noise = O.make_head_inputs(seed + 1, B, 144, 216)
+    with torch.no_grad():
+        pred, loss, cf = m.forward_tokens(x.to(dev), x1.to(dev), y.to(dev), to_dev(noise, dev))
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    check("eval.pred(logits)", pred.cpu(), T(z["pred"]), 1e-4)
+    check("eval.cf", cf.cpu(), T(z["cf"]), 1e-4)
+    check("eval.loss", loss.cpu().view(1), T([float(z["loss"])]).float(), 1e-4)
+    assert int(m.DILR.bn1.num_batches_tracked) == 7
+    check("eval.bn1.running_var untouched", m.DILR.bn1.running_var.cpu(), st["DILR.bn1.running_var"], 0.0)
+    # pseudo labels (index op, bit exact)
+    with torch.no_grad():
+        mu, sg, pl, zz, ent = m.EPRL_oct(x1.to(dev), noise=to_dev(noise["oct"], dev))
+    p = {**O.make_head_params(seed), **ep}
+    _, _, plo, zo, ento, aux = O.eprl_forward_eval(p, "EPRL_oct.", x1, noise["oct"]["eps"])
+    check("eval.eprl.proxy_loss", pl.cpu().view(1), plo.view(1), 1e-4)
+    check("eval.eprl.entropy", ent.cpu().view(1), ento.view(1), 1e-4)
+    labels, keep, count = edrl.ops.pseudo_label(aux["combined"].to(dev), 0.5)
+    assert torch.equal(labels.cpu(), aux["labels"]) and torch.equal(keep.cpu().bool(), aux["keep"]) and int(count) == int(aux["keep"].sum())
+    # fallback: nobody confident -> the most confident sample alone is kept
+    comb = torch.tensor([[0.1, 0.2], [0.4, 0.3], [0.05, 0.0]], device=dev)
+    labels, keep, count = edrl.ops.pseudo_label(comb, 0.5)
+    assert keep.cpu().tolist() == [0, 1, 0] and int(count) == 1 and labels.cpu().tolist() == [1, 0, 0]
+
+
+def test_encoder_eval_mode_vs_oracle(edrl, dev):
+    from oracle import resnet_oracle as RO
+    torch.manual_seed(0)
+    enc = edrl.OCTSliceEncoder(18, 768).to(dev)
+    g = torch.Generator().manual_seed(3)
+    # non-trivial running statistics
+    for n in enc.trunk._bn_names:
+        enc.trunk.get(n + ".running_mean").copy_(0.1 * torch.randn(enc.trunk.get(n + ".running_mean").shape, generator=g))
+        enc.trunk.get(n + ".running_var").copy_(0.5 + torch.rand(enc.trunk.get(n + ".running_var").shape, generator=g))
+    enc.eval()
+    x = torch.rand(2, 1, 3, 64, 64, generator=g)
+    sd = RO.trunk_state(enc.trunk, requires_grad=False)
+    ref, _ = RO.oct_encoder_forward(x.double(), sd, enc.trunk.kind, enc.trunk.blocks,
+                                    enc.token_proj.weight.detach().cpu().double(),
+                                    enc.token_proj.bias.detach().cpu().double(), train=False)
+    with torch.no_grad():
+        tok, _ = enc(x.to(dev))
+    check("encoder_eval_tokens", tok.cpu(), ref, 1e-4)
+    assert int(enc.trunk.get("bn1.num_batches_tracked")) == 0
+
+
+def test_val_loop_and_checkpoint_roundtrip(edrl, dev, tmp_path):
+    """val(): eval-mode forward of the whole model at the reference-native token counts (384^2 fundus -> 144 tokens,
+    216 OCT slices), best-checkpoint save with the reference's {'epoch','state_dict'} layout, reload."""
+    args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
+    torch.manual_seed(0)
+    m = edrl.MedFusion(2, 2, None, args).to(dev)
+    ep, _ = O.make_eval_params(9)
+    m.load_state_dict({k: v for k, v in ep.items()}, strict=False)
+    data, y = edrl.synthetic_batch(2, 384, 384, 216, device=dev)       # OCT slices at 384x384 too (tiny batch)
+    path = str(tmp_path / "best.pth")
+    out = edrl.val(3, [(data, y)], m, best_acc=-1.0, save_path=path)
+    assert out["loss"] == out["loss"] and 0.0 <= out["acc"] <= 1.0
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert ck["epoch"] == 3 and "DILR.projector1.weight" in ck["state_dict"]
+    m2 = edrl.MedFusion(2, 2, None, args)
+    m2.load_state_dict(ck["state_dict"])

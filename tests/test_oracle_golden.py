@@ -104,3 +104,18 @@ def test_label_outside_proxy_dict_raises():
     y = torch.tensor([0, 2])
     with pytest.raises(KeyError):
         O.eprl_forward_train(p, "EPRL_oct.", x1, y, noise["oct"]["eps"], noise["oct"]["mask1"], noise["oct"]["mask2"], 2)
+
+
+def test_eval_branch_golden():
+    z = np.load(os.path.join(GOLD, "head_eval_b4.npz"))
+    B, seed = int(z["B"]), int(z["seed"])
+    p = O.make_head_params(seed)
+    ep, st = O.make_eval_params(seed + 5)
+    x, x1, y, noise = O.make_head_inputs(seed + 1, B, 144, 216)
+    with torch.no_grad():
+        pred, loss, cf, aux = O.medfusion_forward_tokens({**p, **ep}, dict(st), x, x1, y, noise, B, training=False)
+    check("eval.pred", pred, T(z["pred"]), 1e-5); check("eval.cf", cf, T(z["cf"]), 1e-5)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    assert torch.equal(aux["sel_fundus"]["labels"], T(z["labels_fundus"]))
+    assert torch.equal(aux["sel_oct"]["labels"], T(z["labels_oct"]))
+    assert int(st["DILR.bn1.num_batches_tracked"]) == 7       # eval leaves the running statistics alone
