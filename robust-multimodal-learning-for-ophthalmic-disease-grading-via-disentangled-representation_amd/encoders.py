@@ -13,6 +13,7 @@ autograd node whose forward/backward sequence the HIP launchers directly (implic
 convs, two-level BN reductions, fused BN+ReLU(+residual) apply) — no per-layer autograd graph.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -27,6 +28,9 @@ _CFG = {
     34: ("basic", [3, 4, 6, 3], 1),
     50: ("bottleneck", [3, 4, 6, 3], 4),
 }
+
+
+_WGRAD_SIDE_STREAM = os.environ.get("EDRL_WGRAD_STREAM", "1") != "0"
 
 
 def _bn_ws(M, C, device, extra=0):
@@ -129,9 +133,21 @@ class _TrunkFn(torch.autograd.Function):
         grads = {}
         dcur = dout.contiguous()
 
+        # Weight gradients are off the critical chain (dgrad -> BN backward -> dgrad ...): they are issued on a side
+        # stream so the MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm-backward kernels of the main stream.
+        main = torch.cuda.current_stream()
+        side = T.wgrad_stream() if _WGRAD_SIDE_STREAM else None
+
         def conv_bwd(name, dy, inp, stride, pad, need_dx=True, dx_out=None, accumulate=False):
             w = p[name + ".weight"]
-            grads[name + ".weight"] = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+            if side is None:
+                grads[name + ".weight"] = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+            else:
+                side.wait_event(main.record_event())
+                with torch.cuda.stream(side):
+                    dw = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+                dy.record_stream(side); inp.record_stream(side); dw.record_stream(main)
+                grads[name + ".weight"] = dw
             if not need_dx:
                 return None
             return ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
@@ -181,6 +197,8 @@ class _TrunkFn(torch.autograd.Function):
         L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
         draw, _ = bn_bwd("bn1", da0, a0, raw, (m0, r0))
         dx = conv_bwd("conv1", draw, x, 2, 3, need_dx=ctx.needs_x)
+        if side is not None:
+            main.wait_stream(side)
         return (None, dx) + tuple(grads.get(n) for n in T.param_names)
 
 
@@ -252,6 +270,12 @@ class ResNetTrunk(nn.Module):
         return {"weight": p[name + ".weight"], "bias": p[name + ".bias"],
                 "running_mean": self.get(name + ".running_mean"), "running_var": self.get(name + ".running_var"),
                 "momentum": 0.1, "eps": 1e-5}
+
+    def wgrad_stream(self):
+        s = getattr(self, "_wgrad_stream", None)
+        if s is None:
+            s = self._wgrad_stream = torch.cuda.Stream()
+        return s
 
     def bump_batches_tracked(self):
         torch._foreach_add_([self.get(n + ".num_batches_tracked") for n in self._bn_names], 1)

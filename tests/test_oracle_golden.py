@@ -119,3 +119,24 @@ def test_eval_branch_golden():
     assert torch.equal(aux["sel_fundus"]["labels"], T(z["labels_fundus"]))
     assert torch.equal(aux["sel_oct"]["labels"], T(z["labels_oct"]))
     assert int(st["DILR.bn1.num_batches_tracked"]) == 7       # eval leaves the running statistics alone
+
+
+def test_c0_plumbing_epoch_on_cpu(edrl):
+    """BASELINE.json configs[0]: the CPU-runnable plumbing case (ResNet-18 encoders, batch 2, two-view step + Adam) —
+    run through the CPU oracle (the product itself is HIP-only by contract).  Reduced to 64x64 / 4 slices to stay fast."""
+    import types
+    from oracle import step_oracle as SO
+    args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
+    torch.manual_seed(0)
+    m = edrl.MedFusion(2, 2, None, args).train()          # construction only: parameters, no forward on the CPU
+    orc = SO.OracleEDRL(m, dtype=torch.float32)
+    adam = {}
+    losses = []
+    for it in range(2):
+        data, y = edrl.synthetic_batch(2, 64, 64, 4, device="cpu", seed=100 + it)
+        out = orc.train_step(data, y, SO.make_noise(10 + it, 2, 4, 4), SO.make_noise(20 + it, 2, 4, 4), lr=1e-4, adam_state=adam)
+        losses.append(out["total"].item())
+        assert out["pred"].shape == (2, 2) and out["cf1"].shape == (2, 3072)
+        assert all(g is not None for g in out["grads"].values())
+    assert all(l == l and l < 1e3 for l in losses)
+    assert int(orc.state["DILR.bn1.num_batches_tracked"]) == 8     # 4 updates per step (quirk Q5)
