@@ -70,15 +70,18 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
                             float* running_mean, float* running_var, float momentum, float eps,
                             float* save_mean, float* save_rstd, float* scale, float* shift, float* workspace,
                             size_t workspace_bytes, hipStream_t stream);
-/* out = (relu?)((x - mean)*scale + shift [+ residual])   (scale = gamma*rstd, shift = beta) */
+/* out = (relu?)((x - mean)*scale + shift [+ residual])   (scale = gamma*rstd, shift = beta).
+ * relu_mask (optional, dense [M][C/4] bytes, needs ld == C): 4 ReLU sign bits per 4 channels, so the backward
+ * reads 1 byte instead of the 16-byte activation. */
 int edrl_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift,
-                      const float* residual, float* out, long M, int C, long ld, int relu, hipStream_t stream);
-/* Backward of BN(+residual)(+ReLU).  dout = grad of the activated output, out = that output
- * (NULL when no ReLU); dx = grad of the raw input; dres (optional) [+]= masked dout.
+                      const float* residual, float* out, unsigned char* relu_mask, long M, int C, long ld, int relu,
+                      hipStream_t stream);
+/* Backward of BN(+residual)(+ReLU).  dout = grad of the activated output; the ReLU mask comes from relu_mask
+ * (preferred) or from out > 0 (both NULL = no ReLU); dx = grad of the raw input; dres (optional) [+]= masked dout.
  * workspace >= edrl_bn_workspace_bytes(M,C) + 2*C*4 bytes. */
-int edrl_bn_bwd_f32(const float* dout, const float* out, const float* x, const float* save_mean,
-                    const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, int accumulate,
-                    float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
+int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* relu_mask, const float* x,
+                    const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma, float* dbeta,
+                    int accumulate, float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
                     size_t workspace_bytes, hipStream_t stream);
 
 /* 3x3 / stride 2 / pad 1 max pooling on NHWC (encoder stem); idx = window tap of the first max. */

@@ -19,6 +19,7 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ x, const float* __restrict__ dout,
                                                       const float* __restrict__ out,
+                                                      const unsigned char* __restrict__ rmask,
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, long M, int C, long ld,
                                                       float* __restrict__ part) {
@@ -52,7 +53,10 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
         if (MODE == 1) {
 #pragma unroll
           for (int u = 0; u < U; ++u) gv[u] = *reinterpret_cast<const f32x4*>(dout + (r + (long)u * RL) * ld + c);
-          if (out) {
+          if (rmask) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ov[u][0] = (float)rmask[(r + (long)u * RL) * C4 + (c >> 2)];
+          } else if (out) {
 #pragma unroll
             for (int u = 0; u < U; ++u) ov[u] = *reinterpret_cast<const f32x4*>(out + (r + (long)u * RL) * ld + c);
           }
@@ -65,7 +69,11 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
             s1 += d * d;
           } else {
             f32x4 g = gv[u];
-            if (out) {
+            if (rmask) {
+              const int mb = (int)ov[u][0];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) g[e] = (mb >> e) & 1 ? g[e] : 0.f;
+            } else if (out) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) g[e] = ov[u][e] > 0.f ? g[e] : 0.f;
             }
@@ -82,7 +90,11 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
           s1 += d * d;
         } else {
           f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
-          if (out) {
+          if (rmask) {
+            const int mb = rmask[r * C4 + (c >> 2)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (mb >> e) & 1 ? g[e] : 0.f;
+          } else if (out) {
             const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
@@ -207,7 +219,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ residual,
-                                                       float* __restrict__ out, long M, int C, long ld, int relu) {
+                                                       float* __restrict__ out, unsigned char* __restrict__ mask_out,
+                                                       long M, int C, long ld, int relu) {
   const int C4 = C >> 2;
   const long total = M * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -220,6 +233,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     f32x4 v = (xv - mu) * sc + sf;
     if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * ld + c);
     if (relu) {
+      if (mask_out) {   // 4 ReLU sign bits per float4: the backward reads this byte instead of the 16-B activation
+        int mb = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mb |= (v[e] > 0.f ? 1 : 0) << e;
+        mask_out[i] = (unsigned char)mb;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
@@ -229,7 +248,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // g = dout * (out>0);  dx = gamma*rstd*(g - c1 - xhat*c2);  dres (+)= g
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
+    const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ rmask,
+    const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     const float* __restrict__ coef, float* __restrict__ dx, float* __restrict__ dres, int dres_accum, long M,
     int C, long ld) {
@@ -239,7 +259,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const long r = i / C4;
     const int c = (int)(i - r * C4) * 4;
     f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
-    if (out) {
+    if (rmask) {
+      const int mb = rmask[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (mb >> e) & 1 ? g[e] : 0.f;
+    } else if (out) {
       const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
@@ -388,7 +412,7 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
   if (workspace_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
   const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
   hipLaunchKernelGGL(colstat_kernel<0>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, nullptr, nullptr,
-                     nullptr, nullptr, M, C, ld, workspace);
+                     nullptr, nullptr, nullptr, M, C, ld, workspace);
   EDRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M, gamma,
                      beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
@@ -397,33 +421,36 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
 }
 
 int edrl_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift,
-                      const float* residual, float* out, long M, int C, long ld, int relu, hipStream_t st) {
+                      const float* residual, float* out, unsigned char* relu_mask, long M, int C, long ld, int relu,
+                      hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3) || (ld & 3)) return EDRL_EINVAL;
+  if (relu_mask && ld != C) return EDRL_EINVAL;   // the byte mask is dense [M][C/4]
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, mean, scale, shift, residual,
-                     out, M, C, ld, relu);
+                     out, relu_mask, M, C, ld, relu);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
 
 // BN(+ReLU)(+residual) backward.  dout: grad of the post-activation output; out: that output (NULL = no ReLU).
 // dx: grad of the raw (pre-BN) tensor; dres (optional): grad of the residual operand, (+)= dout*mask.
-int edrl_bn_bwd_f32(const float* dout, const float* out, const float* x, const float* save_mean,
-                    const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, int accumulate,
-                    float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
+int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* relu_mask, const float* x,
+                    const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma, float* dbeta,
+                    int accumulate, float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
                     size_t workspace_bytes, hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3) || (ld & 3)) return EDRL_EINVAL;
+  if (relu_mask && ld != C) return EDRL_EINVAL;
   const size_t stats = edrl_bn_workspace_bytes(M, C);
   if (workspace_bytes < stats + (size_t)2 * C * sizeof(float)) return EDRL_ENOSPC;
   float* coef = workspace + stats / sizeof(float);
   const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
-  hipLaunchKernelGGL(colstat_kernel<1>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout, out, save_mean,
-                     save_rstd, M, C, ld, workspace);
+  hipLaunchKernelGGL(colstat_kernel<1>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout, out, relu_mask,
+                     save_mean, save_rstd, M, C, ld, workspace);
   EDRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M,
                      dgamma, dbeta, accumulate, coef);
   EDRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, out, x, save_mean,
-                     save_rstd, gamma, coef, dx, dres, dres_accum, M, C, ld);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, out, relu_mask, x,
+                     save_mean, save_rstd, gamma, coef, dx, dres, dres_accum, M, C, ld);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

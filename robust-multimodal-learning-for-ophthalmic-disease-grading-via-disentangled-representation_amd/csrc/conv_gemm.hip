@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
 // issued in four pieces, one per 8-deep MFMA chunk, so that its address arithmetic and the loads sit in
 // the shadow of the 64-cycle fp32 MFMAs instead of in front of them.  The (tap, channel) decode of the
 // K index advances incrementally (no integer division in the loop).
-template <int BM, int BN, bool DGRAD, int BKT, int OCC>
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n) {
@@ -308,15 +308,55 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   // incremental decode of k = kt*BK + k4 -> (ta, tb, c): tap (kh0 + ta*kstep, kw0 + tb*kstep), channel c
   int c = k4, ta = 0, tb = 0, kk = k4;
   while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
+
+  // FAST (SC % BKT == 0): a K tile never straddles a tap, so every thread of the workgroup changes tap on the
+  // same tile.  The per-row source offsets and the weight tap offset are then recomputed only on a tap change
+  // (every SC/BKT tiles; never for 1x1 convs and Linear layers) and a staging piece costs ~one add + select.
+  long rowoff[A_LD];   // element offset of the row's source pixel for the current tap, -1 = masked
+  long tapoff = 0;     // (kh*KW + kw)*SC of the current tap
+  auto retap = [&]() {
+    const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
+    tapoff = (long)(kh * g.KW + kw) * g.SC;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      int sh, sw;
+      bool ok = rn[i] >= 0;
+      if (DGRAD) {
+        const int th = rh[i] - kh, tw = rw[i] - kw;
+        ok = ok && th >= 0 && tw >= 0;
+        sh = th >> g.sshift; sw = tw >> g.sshift;
+      } else { sh = rh[i] + kh; sw = rw[i] + kw; }
+      ok = ok && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+      rowoff[i] = ok ? (((long)rn[i] * g.SH + sh) * g.SW + sw) * g.ld_src : -1;
+    }
+  };
+  if (FAST) retap();
   auto advance = [&]() {
     c += BKT; kk += BKT;
-    while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
+    if (FAST) {
+      if (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
+    } else {
+      while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
+    }
   };
 
   f32x4 a_st[A_LD], b_st[B_LD];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_piece = [&](int i) {
     const bool kvalid = kk < g.Ktot;   // (a class of the strided dgrad may have no taps at all: Ktot == 0)
+    if (FAST) {
+      {
+        const bool ok = kvalid && rowoff[i] >= 0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (ok ? rowoff[i] + c : 0));
+        a_st[i] = ok ? v : zero4;
+      }
+      if (i < B_LD) {
+        const bool ok = kvalid && wrow[i] >= 0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wm + (ok ? wrow[i] + tapoff + c : 0));
+        b_st[i] = ok ? v : zero4;
+      }
+      return;
+    }
     const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
     {
       int sh, sw;
@@ -430,7 +470,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   }
 }
 
-template <int BM, int BN, bool DGRAD, int BKT, int OCC>
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
                             const float* mul, const GatherGeom& g, hipStream_t st) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
@@ -438,7 +478,7 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC>;
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -479,11 +519,16 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
     // ResNet-50 layer shapes (1024 images): +13 % over K tile 32 / 2 workgroups per CU (profiles/).
     static const int variant = getenv("EDRL_GATHER_VARIANT") ? atoi(getenv("EDRL_GATHER_VARIANT")) : 1;
     if (variant == 0) {   // K tile 32, 2 workgroups per CU (kept for A/B runs)
-      if (narrow) return launch_gather_v2<128, 64, DGRAD, 32, 2>(src, wm, dst, bias, mul, g, st);
-      return launch_gather_v2<128, 128, DGRAD, 32, 2>(src, wm, dst, bias, mul, g, st);
+      if (narrow) return launch_gather_v2<128, 64, DGRAD, 32, 2, false>(src, wm, dst, bias, mul, g, st);
+      return launch_gather_v2<128, 128, DGRAD, 32, 2, false>(src, wm, dst, bias, mul, g, st);
     }
-    if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 3>(src, wm, dst, bias, mul, g, st);
-    return launch_gather_v2<128, 128, DGRAD, 16, 3>(src, wm, dst, bias, mul, g, st);
+    const bool fast = (g.SC % 16 == 0) && variant != 3;
+    if (fast) {
+      if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 3, true>(src, wm, dst, bias, mul, g, st);
+      return launch_gather_v2<128, 128, DGRAD, 16, 3, true>(src, wm, dst, bias, mul, g, st);
+    }
+    if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 3, false>(src, wm, dst, bias, mul, g, st);
+    return launch_gather_v2<128, 128, DGRAD, 16, 3, false>(src, wm, dst, bias, mul, g, st);
   }
   if (narrow) return launch_gather<128, 64, DGRAD, false>(src, wm, dst, bias, mul, g, st);
   return launch_gather<128, 128, DGRAD, false>(src, wm, dst, bias, mul, g, st);

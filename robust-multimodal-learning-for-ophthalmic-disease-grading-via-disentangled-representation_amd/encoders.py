@@ -30,7 +30,10 @@ _CFG = {
 }
 
 
-_WGRAD_SIDE_STREAM = os.environ.get("EDRL_WGRAD_STREAM", "1") != "0"
+# EDRL_WGRAD_STREAM=1 issues the weight-gradient kernels on a side stream (measured +2 % images/s at C1: they overlap
+# the HBM-bound BatchNorm-backward kernels).  Off by default: concurrent streams inflate every per-kernel duration
+# (HIP events and rocprof alike), which would blur the roofline measurement of the dominant kernel.
+_WGRAD_SIDE_STREAM = os.environ.get("EDRL_WGRAD_STREAM", "0") == "1"
 
 
 def _bn_ws(M, C, device, extra=0):
@@ -50,12 +53,14 @@ def _bn_fwd(raw, bn, relu, residual=None):
            P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(mean), P(rstd), P(scale), P(shift),
            P(ws), nbytes)
     out = torch.empty_like(raw)
-    L.call("edrl_bn_apply_f32", P(raw), P(mean), P(scale), P(shift), P(residual), P(out), M, C, C, 1 if relu else 0)
-    return out, mean, rstd
+    mask = torch.empty((M, C // 4), device=dev, dtype=torch.uint8) if relu else None
+    L.call("edrl_bn_apply_f32", P(raw), P(mean), P(scale), P(shift), P(residual), P(out), P(mask), M, C, C,
+           1 if relu else 0)
+    return out, mean, rstd, mask
 
 
-def _bn_bwd(dout, out, raw, mean, rstd, gamma, want_dres):
-    """-> (d_raw, dgamma, dbeta, dres). `out` None means no ReLU on this BN's output."""
+def _bn_bwd(dout, mask, raw, mean, rstd, gamma, want_dres):
+    """-> (d_raw, dgamma, dbeta, dres). `mask` = the ReLU sign-bit bytes written by _bn_fwd (None: no ReLU)."""
     C = raw.shape[-1]
     M = raw.numel() // C
     dev = raw.device
@@ -64,7 +69,7 @@ def _bn_bwd(dout, out, raw, mean, rstd, gamma, want_dres):
     dbeta = torch.empty_like(dgamma)
     dres = torch.empty_like(raw) if want_dres else None
     ws, nbytes = _bn_ws(M, C, dev, extra=2 * C * 4)
-    L.call("edrl_bn_bwd_f32", P(dout), P(out), P(raw), P(mean), P(rstd), P(gamma), P(dgamma), P(dbeta), 0,
+    L.call("edrl_bn_bwd_f32", P(dout), None, P(mask), P(raw), P(mean), P(rstd), P(gamma), P(dgamma), P(dbeta), 0,
            P(d_raw), P(dres), 0, M, C, C, P(ws), nbytes)
     return d_raw, dgamma, dbeta, dres
 
@@ -84,39 +89,39 @@ class _TrunkFn(torch.autograd.Function):
             return ops.conv2d_fwd(inp, p[name + ".weight"], stride=stride, pad=pad)
 
         raw = conv("conv1", x, 2, 3)
-        a0, m0, r0 = _bn_fwd(raw, bnd("bn1", p), True)
+        a0, m0, r0, k0 = _bn_fwd(raw, bnd("bn1", p), True)
         N, H, W, C = a0.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         p0 = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
         idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
         L.call("edrl_maxpool3x3s2_fwd_f32", P(a0), P(p0), P(idx), N, H, W, C)
-        saved["stem"] = (x, raw, a0, m0, r0, idx)
+        saved["stem"] = (x, raw, a0.shape, m0, r0, k0, idx)
         cur = p0
         for blk in T.blocks:
             pre, s = blk["name"], blk["stride"]
             rec = {"x": cur}
             if T.kind == "bottleneck":
                 c1 = conv(pre + ".conv1", cur, 1, 0)
-                a1, m1, r1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
+                a1, m1, r1, k1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
                 c2 = conv(pre + ".conv2", a1, s, 1)
-                a2, m2, r2 = _bn_fwd(c2, bnd(pre + ".bn2", p), True)
+                a2, m2, r2, k2 = _bn_fwd(c2, bnd(pre + ".bn2", p), True)
                 c3 = conv(pre + ".conv3", a2, 1, 0)
-                rec.update(c1=c1, a1=a1, s1=(m1, r1), c2=c2, a2=a2, s2=(m2, r2), c3=c3)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2, a2=a2, s2=(m2, r2), k2=k2, c3=c3)
                 last, last_bn = c3, pre + ".bn3"
             else:
                 c1 = conv(pre + ".conv1", cur, s, 1)
-                a1, m1, r1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
+                a1, m1, r1, k1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
                 c2 = conv(pre + ".conv2", a1, 1, 1)
-                rec.update(c1=c1, a1=a1, s1=(m1, r1), c2=c2)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2)
                 last, last_bn = c2, pre + ".bn2"
             if blk["downsample"]:
                 cd = conv(pre + ".downsample.0", cur, s, 0)
-                idn, md, rd = _bn_fwd(cd, bnd(pre + ".downsample.1", p), False)
+                idn, md, rd, _ = _bn_fwd(cd, bnd(pre + ".downsample.1", p), False)
                 rec.update(cd=cd, sd=(md, rd))
             else:
                 idn = cur
-            out, ml, rl = _bn_fwd(last, bnd(last_bn, p), True, residual=idn)
-            rec.update(out=out, sl=(ml, rl))
+            out, ml, rl, kl = _bn_fwd(last, bnd(last_bn, p), True, residual=idn)
+            rec.update(sl=(ml, rl), kl=kl)
             saved[pre] = rec
             cur = out
         ctx.trunk = T
@@ -153,8 +158,8 @@ class _TrunkFn(torch.autograd.Function):
             return ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
                                     accumulate=accumulate)
 
-        def bn_bwd(name, dy, out, raw, st, want_dres=False):
-            d_raw, dg, db, dres = _bn_bwd(dy, out, raw, st[0], st[1], p[name + ".weight"], want_dres)
+        def bn_bwd(name, dy, mask, raw, st, want_dres=False):
+            d_raw, dg, db, dres = _bn_bwd(dy, mask, raw, st[0], st[1], p[name + ".weight"], want_dres)
             grads[name + ".weight"] = dg
             grads[name + ".bias"] = db
             return d_raw, dres
@@ -164,21 +169,21 @@ class _TrunkFn(torch.autograd.Function):
             rec = saved.pop(pre)
             xin = rec["x"]
             if T.kind == "bottleneck":
-                d3, g = bn_bwd(pre + ".bn3", dcur, rec["out"], rec["c3"], rec["sl"], want_dres=True)
+                d3, g = bn_bwd(pre + ".bn3", dcur, rec["kl"], rec["c3"], rec["sl"], want_dres=True)
             else:
-                d3, g = bn_bwd(pre + ".bn2", dcur, rec["out"], rec["c2"], rec["sl"], want_dres=True)
+                d3, g = bn_bwd(pre + ".bn2", dcur, rec["kl"], rec["c2"], rec["sl"], want_dres=True)
             # Block-input gradient dx = (main path: conv1's dgrad, written first, covers every pixel)
             #                         + (identity: g | downsample: its strided dgrad, accumulated afterwards so that
             #                            only the parity class it reaches is touched — no zero fill, no re-read).
             if T.kind == "bottleneck":
                 da2 = conv_bwd(pre + ".conv3", d3, rec["a2"], 1, 0)
-                d2, _ = bn_bwd(pre + ".bn2", da2, rec["a2"], rec["c2"], rec["s2"])
+                d2, _ = bn_bwd(pre + ".bn2", da2, rec["k2"], rec["c2"], rec["s2"])
                 da1 = conv_bwd(pre + ".conv2", d2, rec["a1"], s, 1)
-                d1, _ = bn_bwd(pre + ".bn1", da1, rec["a1"], rec["c1"], rec["s1"])
+                d1, _ = bn_bwd(pre + ".bn1", da1, rec["k1"], rec["c1"], rec["s1"])
                 c1_stride, c1_pad = 1, 0
             else:
                 da1 = conv_bwd(pre + ".conv2", d3, rec["a1"], 1, 1)
-                d1, _ = bn_bwd(pre + ".bn1", da1, rec["a1"], rec["c1"], rec["s1"])
+                d1, _ = bn_bwd(pre + ".bn1", da1, rec["k1"], rec["c1"], rec["s1"])
                 c1_stride, c1_pad = s, 1
             if blk["downsample"]:
                 dx = conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad)
@@ -191,11 +196,11 @@ class _TrunkFn(torch.autograd.Function):
             del g
             dcur = dx
             del rec
-        x, raw, a0, m0, r0, idx = saved.pop("stem")
-        N, H, W, C = a0.shape
-        da0 = torch.empty_like(a0)
+        x, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
+        N, H, W, C = a0_shape
+        da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.float32)
         L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
-        draw, _ = bn_bwd("bn1", da0, a0, raw, (m0, r0))
+        draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))
         dx = conv_bwd("conv1", draw, x, 2, 3, need_dx=ctx.needs_x)
         if side is not None:
             main.wait_stream(side)

@@ -543,7 +543,7 @@ class BatchNorm1dTrainFn(torch.autograd.Function):
             L.call("edrl_bn_train_stats_f32", P(x), M, C, C, None, None, P(running_mean), P(running_var),
                    float(momentum), float(eps), P(mean), P(rstd), P(scale), P(shift), P(ws), nbytes)
         y = torch.empty_like(x)
-        L.call("edrl_bn_apply_f32", P(x), P(mean), P(scale), P(shift), None, P(y), M, C, C, 0)
+        L.call("edrl_bn_apply_f32", P(x), P(mean), P(scale), P(shift), None, P(y), None, M, C, C, 0)
         ctx.save_for_backward(x, mean, rstd)
         return y
 
@@ -554,7 +554,7 @@ class BatchNorm1dTrainFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         ws, nbytes = _bn_ws(M, C, x.device, extra=2 * C * 4)
-        L.call("edrl_bn_bwd_f32", P(dy), None, P(x), P(mean), P(rstd), None, None, None, 0, P(dx), None, 0, M, C, C,
+        L.call("edrl_bn_bwd_f32", P(dy), None, None, P(x), P(mean), P(rstd), None, None, None, 0, P(dx), None, 0, M, C, C,
                P(ws), nbytes)
         return dx, None, None, None, None, None
 
@@ -754,5 +754,6 @@ def batchnorm_eval(x, running_mean, running_var, gamma=None, beta=None, eps=1e-5
     shift = torch.empty_like(scale)
     L.call("edrl_bn_eval_params_f32", P(gamma), P(beta), P(running_var), float(eps), P(scale), P(shift), C)
     y = torch.empty_like(x)
-    L.call("edrl_bn_apply_f32", P(x), P(running_mean), P(scale), P(shift), P(residual), P(y), M, C, C, 1 if relu else 0)
+    L.call("edrl_bn_apply_f32", P(x), P(running_mean), P(scale), P(shift), P(residual), P(y), None, M, C, C,
+           1 if relu else 0)
     return y

@@ -50,11 +50,11 @@ def test_batchnorm_moments_and_determinism_c1_layer(edrl, dev):
     x = torch.randn(N, H, H, C, device=dev, generator=g) * 3 + 1.5
     bn = {"weight": torch.ones(C, device=dev), "bias": torch.zeros(C, device=dev), "running_mean": torch.zeros(C, device=dev),
           "running_var": torch.ones(C, device=dev), "momentum": 0.1, "eps": 1e-5}
-    y, mean, rstd = encoders._bn_fwd(x, bn, False)
+    y, mean, rstd, _ = encoders._bn_fwd(x, bn, False)
     yd = y.double().view(-1, C)
     assert yd.mean(0).abs().max().item() < 1e-5, "normalised output must have zero mean per channel"
     assert (yd.var(0, unbiased=False) - 1).abs().max().item() < 1e-4, "and unit variance"
-    y2, mean2, _ = encoders._bn_fwd(x, dict(bn), False)
+    y2, mean2, _, _ = encoders._bn_fwd(x, dict(bn), False)
     assert torch.equal(y, y2) and torch.equal(mean, mean2), "BN statistics must be deterministic"
 
 

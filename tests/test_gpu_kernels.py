@@ -117,11 +117,13 @@ def test_batchnorm_train(edrl, dev, M, C):
     bn = {"weight": gamma.to(dev), "bias": beta.to(dev), "running_mean": rm.to(dev), "running_var": rv.to(dev),
           "momentum": 0.1, "eps": 1e-5}
     xh = x.to(dev).view(1, 1, M, C)
-    out, mean, rstd = encoders._bn_fwd(xh, bn, True, residual=res.to(dev).view(1, 1, M, C))
+    out, mean, rstd, mask = encoders._bn_fwd(xh, bn, True, residual=res.to(dev).view(1, 1, M, C))
+    bits = torch.stack([(mask.cpu() >> e) & 1 for e in range(4)], dim=-1).view(M, C).bool()
+    assert torch.equal(bits, out.view(M, C).cpu() > 0), "ReLU sign-bit mask must be bit exact"
     check("bn_fwd", out.view(M, C).cpu(), y, 1e-5)
     check("bn_running_mean", bn["running_mean"].cpu(), rm_ref, 1e-5)
     check("bn_running_var", bn["running_var"].cpu(), rv_ref, 1e-5)
-    d_raw, dg, db, dres = encoders._bn_bwd(dy.to(dev).view(1, 1, M, C), out, xh, mean, rstd, bn["weight"], True)
+    d_raw, dg, db, dres = encoders._bn_bwd(dy.to(dev).view(1, 1, M, C), mask, xh, mean, rstd, bn["weight"], True)
     check("bn_dx", d_raw.view(M, C).cpu(), xd.grad, 2e-5)
     check("bn_dgamma", dg.cpu(), gd.grad, 2e-5)
     check("bn_dbeta", db.cpu(), bd.grad, 2e-5)
