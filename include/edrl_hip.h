@@ -194,6 +194,14 @@ int edrl_entropy_rows_f32(const float* x, float* out, int R, int C, hipStream_t 
 int edrl_bn_eval_params_f32(const float* gamma, const float* beta, const float* running_var, float eps, float* scale,
                             float* shift, int C, hipStream_t stream);
 
+/* ---- SURVEY §8(f) rows 3-4 ---- */
+/* out = clip(x + sigma*noise, 0, 1): the high-noise twin view of data_harvard.py:769-783 made on the device. */
+int edrl_twin_view_f32(const float* x, const float* noise, float* out, long n, float sigma, hipStream_t stream);
+/* compute_kl_divergence(p, m) = mean_b sum_c p log(p/m) (code/MMD.py:92-95; compute_js_divergence :76-90 composes it). */
+int edrl_kl_rows_fwd_f32(const float* p, const float* m, float* out, int B, int C, hipStream_t stream);
+int edrl_kl_rows_bwd_f32(const float* dloss, const float* p, const float* m, float* dp, float* dm, int B, int C,
+                         hipStream_t stream);
+
 /* ---- MK-MMD (mmd.hip; code/MMD.py:3-74) ------------------------------------------------- */
 int edrl_rowsq_f32(const float* x, float* sq, int n, int d, long ld, hipStream_t stream);
 /* G = total@total^T [n][n], sq [n]; loss [1]; saved [3] = {bandwidth, signed sum, loss}. */

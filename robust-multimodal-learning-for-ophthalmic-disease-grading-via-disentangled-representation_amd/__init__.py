@@ -8,12 +8,12 @@ Compute lives in libedrl_hip.so (hand-written HIP, C-ABI in include/edrl_hip.h);
 package never builds or falls back: a missing library raises on first use.
 """
 from . import _lib, ops
-from .mmd import MK_MMD
+from .mmd import MK_MMD, compute_js_divergence, compute_kl_divergence
 from .medfusion import MedFusion, EPRL, PoE, DILR, AttentionModel, off_diagonal
 from .encoders import ResNetTrunk, FundusEncoder, OCTSliceEncoder
-from .train import train_step, train, val, synthetic_batch
+from .train import train_step, train, val, synthetic_batch, device_twin_views
 from .dist import GradSync, broadcast_parameters
 
-__all__ = ["MedFusion", "EPRL", "PoE", "DILR", "AttentionModel", "off_diagonal", "MK_MMD", "ResNetTrunk",
-           "FundusEncoder", "OCTSliceEncoder", "train_step", "train", "val", "synthetic_batch", "ops", "GradSync",
+__all__ = ["MedFusion", "EPRL", "PoE", "DILR", "AttentionModel", "off_diagonal", "MK_MMD", "compute_js_divergence", "compute_kl_divergence", "ResNetTrunk",
+           "FundusEncoder", "OCTSliceEncoder", "train_step", "train", "val", "synthetic_batch", "device_twin_views", "ops", "GradSync",
            "broadcast_parameters"]

@@ -578,7 +578,46 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   const int ohw = g.OH * g.OW;
 
   f32x4 a_st[A_LD], b_st[B_LD];
+  // Vector path: the (n, oh, ow) decode of each staged pixel row advances incrementally from tile to tile (BKT pixels
+  // per tile; no division in the loop) and the loads are branch-free (clamped address + select) so that they issue
+  // back to back ahead of the MFMA chain.
+  int bn_[B_LD], boh[B_LD], bow[B_LD];
+  long bp[B_LD], ap[A_LD];
+  if (VEC) {
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const long p = t_begin * BKT + (tid + 256 * i) / BC4;
+      bp[i] = p;
+      const long n = p / ohw;
+      const int rem = (int)(p - n * ohw);
+      bn_[i] = (int)n; boh[i] = rem / g.OW; bow[i] = rem - boh[i] * g.OW;
+    }
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) ap[i] = t_begin * BKT + (tid + 256 * i) / AC4;
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_tile_vec = [&]() {   // loads the tile the running state points at, then advances the state by one tile
+    const int co = co0 + ac4 * 4;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const bool ok = ap[i] < g.P && co < g.Co;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (ok ? ap[i] * g.ld_dy + co : 0));
+      a_st[i] = ok ? v : zero4;
+      ap[i] += BKT;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int sh = boh[i] * g.stride - g.pad + kkh, sw = bow[i] * g.stride - g.pad + kkw;
+      const bool ok = kvalid && bp[i] < g.P && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+      const long off = ok ? (((long)bn_[i] * g.SH + sh) * g.SW + sw) * g.ld_x + kc : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+      b_st[i] = ok ? v : zero4;
+      bp[i] += BKT; bow[i] += BKT;
+      while (bow[i] >= g.OW) { bow[i] -= g.OW; if (++boh[i] == g.OH) { boh[i] = 0; ++bn_[i]; } }
+    }
+  };
   auto load_tile = [&](long t) {
+    if (VEC) { load_tile_vec(); return; }
     const long p0 = t * BKT;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
@@ -586,9 +625,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
       const long p = p0 + row;
       const int co = co0 + ac4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (VEC) {
-        if (p < g.P && co < g.Co) v = *reinterpret_cast<const f32x4*>(dy + p * g.ld_dy + co);
-      } else if (p < g.P) {
+      if (p < g.P) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (co + e < g.Co) v[e] = dy[p * g.ld_dy + co + e];
@@ -604,26 +641,16 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
         const int n = (int)(p / ohw);
         const int rem = (int)(p - (long)n * ohw);
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        if (VEC) {
-          if (kvalid) {
-            const int sh = oh * g.stride - g.pad + kkh, sw = ow * g.stride - g.pad + kkw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ke = kcol + e;
+          if (ke < g.Ktot) {
+            const int tap = ke / g.SC, c = ke - tap * g.SC;
+            const int kh = tap / g.KW, kw = tap - kh * g.KW;
+            const int sh = oh * g.stride - g.pad + kh, sw = ow * g.stride - g.pad + kw;
             if (sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW) {
               const long pix = ((long)n * g.SH + sh) * g.SW + sw;
-              v = *reinterpret_cast<const f32x4*>(x + pix * g.ld_x + kc);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int ke = kcol + e;
-            if (ke < g.Ktot) {
-              const int tap = ke / g.SC, c = ke - tap * g.SC;
-              const int kh = tap / g.KW, kw = tap - kh * g.KW;
-              const int sh = oh * g.stride - g.pad + kh, sw = ow * g.stride - g.pad + kw;
-              if (sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW) {
-                const long pix = ((long)n * g.SH + sh) * g.SW + sw;
-                v[e] = x[pix * g.ld_x + c];
-              }
+              v[e] = x[pix * g.ld_x + c];
             }
           }
         }
@@ -727,7 +754,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
 }
 
 #define WG_BK 16
-#define WG_OCC 3
+#define WG_OCC 4
 template <int BM, int BN, bool VEC>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st) {

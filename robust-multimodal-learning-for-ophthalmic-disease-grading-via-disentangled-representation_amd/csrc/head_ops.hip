@@ -580,6 +580,32 @@ __global__ void argmax_rows_kernel(const float* __restrict__ x, long long* __res
 }
 
 
+// ------------------------------------------------------------------ twin-view noise, KL/JS of soft labels
+// out = clip(x + sigma * noise, 0, 1)   — the Gaussian high-noise view of data_harvard.py:769-783 on the device
+__global__ __launch_bounds__(256) void twin_view_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                        float* __restrict__ out, long n, float sigma) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = fminf(fmaxf(x[i] + sigma * noise[i], 0.f), 1.f);
+}
+// compute_kl_divergence(p, m) = mean_b sum_c p log(p/m)   (code/MMD.py:92-95); single block
+__global__ __launch_bounds__(256) void kl_rows_fwd_kernel(const float* __restrict__ p, const float* __restrict__ m,
+                                                          float* __restrict__ out, int B, int C) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B * C; i += 256) s += p[i] * logf(p[i] / m[i]);
+  s = edrl_block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s / (float)B;
+}
+__global__ __launch_bounds__(256) void kl_rows_bwd_kernel(const float* __restrict__ dloss, const float* __restrict__ p,
+                                                          const float* __restrict__ m, float* __restrict__ dp,
+                                                          float* __restrict__ dm, int B, int C) {
+  const float g = dloss[0] / (float)B;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * C; i += gridDim.x * blockDim.x) {
+    dp[i] = g * (logf(p[i] / m[i]) + 1.f);
+    dm[i] = -g * p[i] / m[i];
+  }
+}
+
 // ------------------------------------------------------------------ eval-branch helpers (fusion_net.py:152-218)
 // y[r][:] = softmax(x[r][:]); one wave per row
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C) {
@@ -655,6 +681,25 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const flo
 
 extern "C" {
 
+int edrl_twin_view_f32(const float* x, const float* noise, float* out, long n, float sigma, hipStream_t st) {
+  if (n <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(twin_view_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, noise, out, n, sigma);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_kl_rows_fwd_f32(const float* p, const float* m, float* out, int B, int C, hipStream_t st) {
+  if (B <= 0 || C <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(1), dim3(256), 0, st, p, m, out, B, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_kl_rows_bwd_f32(const float* dloss, const float* p, const float* m, float* dp, float* dm, int B, int C,
+                         hipStream_t st) {
+  if (B <= 0 || C <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3(ew_grid((long)B * C)), dim3(256), 0, st, dloss, p, m, dp, dm, B, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
 int edrl_softmax_rows_f32(const float* x, float* y, int R, int C, hipStream_t st) {
   if (R <= 0 || C <= 0) return EDRL_EINVAL;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(edrl_cdiv(R, 4)), dim3(256), 0, st, x, y, R, C);

@@ -757,3 +757,44 @@ def batchnorm_eval(x, running_mean, running_var, gamma=None, beta=None, eps=1e-5
     L.call("edrl_bn_apply_f32", P(x), P(running_mean), P(scale), P(shift), P(residual), P(y), None, M, C, C,
            1 if relu else 0)
     return y
+
+
+class KlRowsFn(torch.autograd.Function):
+    """compute_kl_divergence(p, m) (code/MMD.py:92-95)."""
+
+    @staticmethod
+    def forward(ctx, p, m):
+        p = _chk(p, "kl.p", False).contiguous(); m = _chk(m, "kl.m", False).contiguous()
+        out = torch.empty((1,), device=p.device, dtype=torch.float32)
+        L.call("edrl_kl_rows_fwd_f32", P(p), P(m), P(out), p.shape[0], p.shape[1])
+        ctx.save_for_backward(p, m)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        p, m = ctx.saved_tensors
+        dp = torch.empty_like(p); dm = torch.empty_like(m)
+        L.call("edrl_kl_rows_bwd_f32", P(dloss.contiguous().view(1)), P(p), P(m), P(dp), P(dm), p.shape[0], p.shape[1])
+        return dp, dm
+
+
+class AxpbyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        ctx.ab = (alpha, beta)
+        return ew(EW_AXPBY, _chk(a, "axpby.a", False), _chk(b, "axpby.b", False).contiguous(), alpha=alpha, beta=beta).view(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return ew(EW_SCALE, g, alpha=ctx.ab[0]).view(g.shape), ew(EW_SCALE, g, alpha=ctx.ab[1]).view(g.shape), None, None
+
+
+def twin_view(x, sigma=0.5, noise=None):
+    """Device-side high-noise view: clip(x + sigma*N(0,1), 0, 1) (data_harvard.py:769-783); RNG draw by torch."""
+    x = _chk(x, "twin.x", False).contiguous()
+    if noise is None:
+        noise = torch.randn_like(x)
+    out = torch.empty_like(x)
+    L.call("edrl_twin_view_f32", P(x), P(noise), P(out), x.numel(), float(sigma))
+    return out

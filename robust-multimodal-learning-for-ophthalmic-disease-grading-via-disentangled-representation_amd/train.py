@@ -28,6 +28,15 @@ def synthetic_batch(batch, H=224, W=224, S=32, device="cuda", seed=1234, rank=0,
     return ([f_low.to(dev), o_low.to(dev)], [f_high.to(dev), o_high.to(dev)]), y.to(dev)
 
 
+def device_twin_views(fundus_low, oct_low, sigma=0.5, drop_oct_high=False):
+    """make the high-noise view on the device from the resident low-noise view
+    (Gaussian N(0, sigma^2) + clip, data_harvard.py:769-783; OCT-dropped = zeros, :333-334) instead of per-sample
+    numpy on loader workers + a synchronous H2D copy (fusion_train.py:181-184)."""
+    f_high = ops.twin_view(fundus_low, sigma)
+    o_high = torch.zeros_like(oct_low) if drop_oct_high else ops.twin_view(oct_low, sigma)
+    return [fundus_low, oct_low], [f_high, o_high]
+
+
 def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None, grad_sync=None):
     """One iteration of the loop body at fusion_train.py:176-225. Returns device tensors, no host sync.
     `grad_sync` (optional): called after backward, before optimizer.step (DP gradient all-reduce)."""

@@ -90,3 +90,21 @@ def test_val_loop_and_checkpoint_roundtrip(edrl, dev, tmp_path):
     assert ck["epoch"] == 3 and "DILR.projector1.weight" in ck["state_dict"]
     m2 = edrl.MedFusion(2, 2, None, args)
     m2.load_state_dict(ck["state_dict"])
+
+
+def test_js_divergence_and_twin_view(edrl, dev):
+    """compute_js_divergence (code/MMD.py:76-95, formula restated inline) and the device twin view."""
+    g = torch.Generator().manual_seed(5)
+    p = torch.softmax(torch.randn(6, 2, generator=g), 1); q = torch.softmax(torch.randn(6, 2, generator=g), 1)
+    pd, qd = p.double().requires_grad_(True), q.double().requires_grad_(True)
+    md = 0.5 * (pd + qd)
+    js = 0.5 * (torch.sum(pd * torch.log(pd / md), dim=1).mean() + torch.sum(qd * torch.log(qd / md), dim=1).mean())
+    js.backward()
+    pg, qg = p.to(dev).requires_grad_(True), q.to(dev).requires_grad_(True)
+    jg = edrl.compute_js_divergence(pg, qg); jg.backward()
+    check("js", jg.cpu().view(1), js.view(1), 1e-5)
+    check("js_dp", pg.grad.cpu(), pd.grad, 1e-4); check("js_dq", qg.grad.cpu(), qd.grad, 1e-4)
+    x = torch.rand(4, 3, 8, 8, generator=g); n = torch.randn(4, 3, 8, 8, generator=g)
+    out = edrl.ops.twin_view(x.to(dev), 0.5, n.to(dev))
+    check("twin_view", out.cpu(), (x.double() + 0.5 * n.double()).clamp(0, 1), 1e-6)
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
