@@ -48,6 +48,7 @@ struct GatherGeom {
 
 #define GF_RELU 1
 #define GF_ACCUM 2
+#define GF_VEC_EPI 4   // set by the host when the float4 epilogue is legal (alignment, NC % 4 == 0)
 
 template <int BM, int BN, bool DGRAD, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
@@ -341,19 +342,20 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   };
 
   f32x4 a_st[A_LD], b_st[B_LD];
+  bool a_ok[A_LD], b_ok[B_LD];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_piece = [&](int i) {
     const bool kvalid = kk < g.Ktot;   // (a class of the strided dgrad may have no taps at all: Ktot == 0)
-    if (FAST) {
+    if (FAST) {   // raw load now, zero-select at store time (keeps the wait for the data off the MFMA chain's head)
       {
         const bool ok = kvalid && rowoff[i] >= 0;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (ok ? rowoff[i] + c : 0));
-        a_st[i] = ok ? v : zero4;
+        a_ok[i] = ok;
+        a_st[i] = *reinterpret_cast<const f32x4*>(src + (ok ? rowoff[i] + c : 0));
       }
       if (i < B_LD) {
         const bool ok = kvalid && wrow[i] >= 0;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(wm + (ok ? wrow[i] + tapoff + c : 0));
-        b_st[i] = ok ? v : zero4;
+        b_ok[i] = ok;
+        b_st[i] = *reinterpret_cast<const f32x4*>(wm + (ok ? wrow[i] + tapoff + c : 0));
       }
       return;
     }
@@ -384,10 +386,10 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     float* b = Bs + buf * BN * LDKT;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = a_st[i];
+      *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = (!FAST || a_ok[i]) ? a_st[i] : zero4;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<f32x4*>(b + (r0 + RPP * i) * LDKT + k4) = b_st[i];
+      *reinterpret_cast<f32x4*>(b + (r0 + RPP * i) * LDKT + k4) = (!FAST || b_ok[i]) ? b_st[i] : zero4;
   };
 
   f32x16 acc[TM][TN];
@@ -410,6 +412,14 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     advance();   // decode state of tile kt+1 (past the end: kvalid is false and the pieces load zeros)
     const float* a = As + buf * BM * LDKT + (wm0 + li) * LDKT + 4 * lh;
     const float* b = Bs + buf * BN * LDKT + (wn0 + li) * LDKT + 4 * lh;
+    // The next tile's global loads are issued FIRST (pinned with a scheduling barrier): they then have the whole
+    // tile's MFMA chain (>= 2048 cycles) to land before the ds_write at the bottom.  Left to itself the compiler
+    // sinks them to the end of the chain (to shorten live ranges) and the wave stalls on vmcnt every tile.
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) load_piece(i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // fragment registers are double buffered: chunk kc+1's LDS reads are issued ahead of chunk kc's 16 MFMAs
     f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDKT + (kc + 1) * 8);
       }
-      load_piece(kc);
+      if (!FAST) load_piece(kc);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -434,11 +444,60 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
     }
+    if (FAST) __builtin_amdgcn_sched_barrier(0);   // the zero-selects + ds_writes (and their vmcnt wait) stay below the chain
     store_tile(buf ^ 1);
     __syncthreads();
   }
 
   const bool relu = g.flags & GF_RELU, accum = g.flags & GF_ACCUM;
+  if (g.flags & GF_VEC_EPI) {
+    // Vector epilogue: each wave transposes its accumulators through LDS (the K-loop buffers are free now) so that a
+    // lane owns 4 consecutive channels of one pixel: 16-B stores, 16 lanes per 256-B row segment, instead of 64
+    // scalar stores per lane.  Bias / ReLU / mask / accumulate are applied on the float4.
+    constexpr int SLD = WN + 4;            // padded staging row (floats)
+    constexpr int C4 = WN / 4;             // float4 per staged row
+    constexpr int RPP2 = 64 / C4;          // rows per pass of the wave
+    float* stage = smem + wave * 32 * SLD;
+    const int srow = lane / C4, sc4 = lane % C4;
+    const int n = n0 + wn0 + sc4 * 4;
+    f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias && n < g.NC) bv4 = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 32 / RPP2; ++t) {
+        const int row = t * RPP2 + srow;
+        const long m = m0 + wm0 + i * 32 + row;
+        if (m < g.M && n < g.NC) {
+          long pix = m;
+          if (DGRAD && g.step > 1) {
+            const int ohw = g.OHs * g.OWs;
+            const int nn = (int)(m / ohw);
+            const int rem = (int)(m - (long)nn * ohw);
+            const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+            pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+          }
+          f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SLD + sc4 * 4) + bv4;
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (mul) v *= *reinterpret_cast<const f32x4*>(mul + pix * g.ld_aux + n);
+          float* p = dst + pix * g.ld_dst + n;
+          if (accum) v += *reinterpret_cast<const f32x4*>(p);
+          *reinterpret_cast<f32x4*>(p) = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + li;
@@ -514,7 +573,12 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
   const bool vec = (g.SC % 4 == 0) && (g.ld_src % 4 == 0) && (g.Kfull % 4 == 0) &&
                    (((uintptr_t)src & 15) == 0) && (((uintptr_t)wm & 15) == 0);
   const bool narrow = g.NC <= 64;
+  GatherGeom gv = g;
+  if (vec && (g.NC % 4 == 0) && (g.ld_dst % 4 == 0) && (((uintptr_t)dst & 15) == 0) &&
+      (!bias || ((uintptr_t)bias & 15) == 0) && (!mul || ((g.ld_aux % 4 == 0) && ((uintptr_t)mul & 15) == 0)))
+    gv.flags |= GF_VEC_EPI;
   if (vec) {
+    const GatherGeom& g = gv;
     // K tile 16 -> 40 KiB of LDS and 128 VGPRs per workgroup: 3 workgroups (12 waves) per CU.  Measured on the
     // ResNet-50 layer shapes (1024 images): +13 % over K tile 32 / 2 workgroups per CU (profiles/).
     static const int variant = getenv("EDRL_GATHER_VARIANT") ? atoi(getenv("EDRL_GATHER_VARIANT")) : 1;
@@ -744,13 +808,31 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
 }
 
 // dW[i] = (accumulate ? dW[i] : 0) + sum_s part[s][i]   (fixed order: deterministic)
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n,
-                                     int splits, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += part[(long)z * n + i];
-  dw[i] = accumulate ? dw[i] + s : s;
+// float4 per lane, 8 slabs in flight per iteration (the slab count reaches several hundred for the small layers).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n,
+                                                            int splits, int accumulate) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 3 < n && (n & 3) == 0) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 7 < splits; z += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (long)(z + u) * n + i4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(part + (long)z * n + i4);
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i4);
+    *reinterpret_cast<f32x4*>(dw + i4) = s;
+  } else {
+    for (long i = i4; i < n && i < i4 + 4; ++i) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += part[(long)z * n + i];
+      dw[i] = accumulate ? dw[i] + s : s;
+    }
+  }
 }
 
 #define WG_BK 16
@@ -901,7 +983,7 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
              : launch_wgrad<128, 128, false>(dy, x, workspace, g, splits, st);
   if (rc) return rc;
   const long n = (long)Co * g.Ktot;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(edrl_cdiv(n, 256)), dim3(256), 0, st, workspace, dw, n,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n,
                      splits, accumulate);
   EDRL_LAUNCH_CHECK();
   return 0;
