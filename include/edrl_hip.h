@@ -43,6 +43,15 @@ int edrl_conv2d_nhwc_fwd_f32(const float* x, const float* w, const float* bias, 
                              int KW, int stride, int pad, long ld_x, long ld_y, long ld_aux, int flags,
                              hipStream_t stream);
 
+/* Same convolution (no bias / activation) with the BatchNorm statistics of its output fused into the epilogue:
+ * stat_part [edrl_conv_stats_chunks(N,Ho,Wo)][3][Co] receives per-128-row chunk shifted moments (sum (y-K), sum (y-K)^2, K
+ * with K = the chunk's first row), to be reduced by edrl_bn_finalize_partials_f32(rows_per_chunk = 128).
+ * stat_shift is reserved (may be NULL).  Needs Ci % 16 == 0. */
+long edrl_conv_stats_chunks(int N, int Ho, int Wo);
+int edrl_conv2d_nhwc_fwd_stats_f32(const float* x, const float* w, float* y, const float* stat_shift, float* stat_part,
+                                   size_t stat_part_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                                   int KH, int KW, int stride, int pad, hipStream_t stream);
+
 /* Data gradient (autograd of the above): dx [+]= conv_transpose(dy, w).
  * wt is w permuted to [Ci,KH,KW,Co] by edrl_permute_weight_f32. */
 int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int Hi, int Wi, int Ci,
@@ -70,6 +79,14 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
                             float* running_mean, float* running_var, float momentum, float eps,
                             float* save_mean, float* save_rstd, float* scale, float* shift, float* workspace,
                             size_t workspace_bytes, hipStream_t stream);
+/* Reduce chunk partials [nchunks][3][C] (shifted moments; chunk k = rows [k*rows_per_chunk, ...)) to the batch statistics and
+ * the BN affine, exactly as the second half of edrl_bn_train_stats_f32.  group_ws (optional, fp64,
+ * edrl_bn_finalize_group_ws_bytes) enables the two-stage reduction used for large chunk counts. */
+size_t edrl_bn_finalize_group_ws_bytes(long nchunks, int C);
+int edrl_bn_finalize_partials_f32(const float* part, long nchunks, int rows_per_chunk, long M, int C, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                  float* save_mean, float* save_rstd, float* scale, float* shift, double* group_ws,
+                                  size_t group_ws_bytes, hipStream_t stream);
 /* out = (relu?)((x - mean)*scale + shift [+ residual])   (scale = gamma*rstd, shift = beta).
  * relu_mask (optional, dense [M][C/4] bytes, needs ld == C): 4 ReLU sign bits per 4 channels, so the backward
  * reads 1 byte instead of the 16-byte activation. */

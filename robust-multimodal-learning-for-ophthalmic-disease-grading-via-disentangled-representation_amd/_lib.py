@@ -20,6 +20,7 @@ _CTYPE = {
     "long": ctypes.c_long,
     "size_t": ctypes.c_size_t,
     "float": ctypes.c_float,
+    "double": ctypes.c_double,
     "hipStream_t": ctypes.c_void_p,
 }
 
@@ -29,7 +30,7 @@ def parse_header(path=HEADER_PATH):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|size_t)\s+(edrl_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int|size_t|long)\s+(edrl_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         argtypes = []
         for a in args.split(","):

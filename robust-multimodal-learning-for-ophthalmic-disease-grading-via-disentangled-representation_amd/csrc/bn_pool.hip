@@ -151,7 +151,8 @@ __device__ __forceinline__ void combine_partials(const float* part, int nchunks,
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nchunks, int C,
-                                                          long M, const float* __restrict__ gamma,
+                                                          long M, int rows_per_chunk,
+                                                          const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float momentum,
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   double a0 = 0.0;
   if (c < C)
     for (int k = q; k < nchunks; k += FIN_LANES) {
-      const long r0 = (long)k * BN_ROWS_PER_CHUNK;
-      const double n = (double)((M - r0) < BN_ROWS_PER_CHUNK ? (M - r0) : BN_ROWS_PER_CHUNK);
+      const long r0 = (long)k * rows_per_chunk;
+      const double n = (double)((M - r0) < rows_per_chunk ? (M - r0) : rows_per_chunk);
       a0 += n * (double)part[(long)k * 3 * C + 2 * C + c] + (double)part[(long)k * 3 * C + c];
     }
   const double mu = fin_lane_sum(a0, sh) / (double)M;
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   double a1 = 0.0;
   if (c < C)
     for (int k = q; k < nchunks; k += FIN_LANES) {
-      const long r0 = (long)k * BN_ROWS_PER_CHUNK;
-      const double n = (double)((M - r0) < BN_ROWS_PER_CHUNK ? (M - r0) : BN_ROWS_PER_CHUNK);
+      const long r0 = (long)k * rows_per_chunk;
+      const double n = (double)((M - r0) < rows_per_chunk ? (M - r0) : rows_per_chunk);
       const double dk = mu - (double)part[(long)k * 3 * C + 2 * C + c];
       a1 += (double)part[(long)k * 3 * C + C + c] - 2.0 * dk * (double)part[(long)k * 3 * C + c] + n * dk * dk;
     }
@@ -195,6 +196,76 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
+  }
+}
+
+// Two-stage variant for large chunk counts (the conv-epilogue partials have one chunk per 128 rows: up to ~10^5):
+// stage A reduces groups of FIN_GROUP chunks to (n_g, mean_g, M2_g) in fp64 with many workgroups, stage B merges the
+// groups (Chan et al.) and finalises.  Same arithmetic as bn_finalize_kernel, just more parallel.
+#define FIN_GROUP 64
+__global__ __launch_bounds__(256) void bn_group_kernel(const float* __restrict__ part, int nchunks, int C, long M,
+                                                       int rows_per_chunk, double* __restrict__ gout) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
+  const int k0 = blockIdx.y * FIN_GROUP;
+  int k1 = k0 + FIN_GROUP;
+  if (k1 > nchunks) k1 = nchunks;
+  long rbeg = (long)k0 * rows_per_chunk, rend = (long)k1 * rows_per_chunk;
+  if (rend > M) rend = M;
+  const double ng = (double)(rend - rbeg);
+  double a0 = 0.0;
+  if (c < C)
+    for (int k = k0 + q; k < k1; k += FIN_LANES) {
+      const long r0 = (long)k * rows_per_chunk;
+      const double n = (double)((M - r0) < rows_per_chunk ? (M - r0) : rows_per_chunk);
+      a0 += n * (double)part[(long)k * 3 * C + 2 * C + c] + (double)part[(long)k * 3 * C + c];
+    }
+  const double mu = fin_lane_sum(a0, sh) / ng;
+  double a1 = 0.0;
+  if (c < C)
+    for (int k = k0 + q; k < k1; k += FIN_LANES) {
+      const long r0 = (long)k * rows_per_chunk;
+      const double n = (double)((M - r0) < rows_per_chunk ? (M - r0) : rows_per_chunk);
+      const double dk = mu - (double)part[(long)k * 3 * C + 2 * C + c];
+      a1 += (double)part[(long)k * 3 * C + C + c] - 2.0 * dk * (double)part[(long)k * 3 * C + c] + n * dk * dk;
+    }
+  const double m2 = fin_lane_sum(a1, sh);
+  if (q == 0 && c < C) {
+    double* o = gout + (long)blockIdx.y * 3 * C;
+    o[c] = ng; o[C + c] = mu; o[2 * C + c] = m2;
+  }
+}
+__global__ __launch_bounds__(64) void bn_finalize_groups_kernel(const double* __restrict__ gin, int G, int C, long M,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, float momentum,
+                                                                float eps, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out, float* __restrict__ scale,
+                                                                float* __restrict__ shift) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int gI = 0; gI < G; ++gI) s += gin[(long)gI * 3 * C + c] * gin[(long)gI * 3 * C + C + c];
+  const double mu = s / (double)M;
+  double m2 = 0.0;
+  for (int gI = 0; gI < G; ++gI) {
+    const double d = gin[(long)gI * 3 * C + C + c] - mu;
+    m2 += gin[(long)gI * 3 * C + 2 * C + c] + gin[(long)gI * 3 * C + c] * d * d;
+  }
+  double var = m2 / (double)M;
+  if (var < 0.0) var = 0.0;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  const float muf = (float)mu;
+  mean_out[c] = muf;
+  rstd_out[c] = rs;
+  const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  scale[c] = gm * rs;
+  shift[c] = bt;
+  if (running_mean) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
 }
 
@@ -414,8 +485,39 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
   hipLaunchKernelGGL(colstat_kernel<0>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, nullptr, nullptr,
                      nullptr, nullptr, nullptr, M, C, ld, workspace);
   EDRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M, gamma,
-                     beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M,
+                     BN_ROWS_PER_CHUNK, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale,
+                     shift);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Second half of edrl_bn_train_stats_f32 for chunk partials produced elsewhere (the conv epilogue,
+// edrl_conv2d_nhwc_fwd_stats_f32): part [nchunks][3][C], chunk k covering rows [k*rows_per_chunk, ...).
+size_t edrl_bn_finalize_group_ws_bytes(long nchunks, int C) {
+  return (size_t)((nchunks + FIN_GROUP - 1) / FIN_GROUP) * 3 * C * sizeof(double);
+}
+int edrl_bn_finalize_partials_f32(const float* part, long nchunks, int rows_per_chunk, long M, int C, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                  float* save_mean, float* save_rstd, float* scale, float* shift, double* group_ws,
+                                  size_t group_ws_bytes, hipStream_t st) {
+  if (M <= 0 || C <= 0 || nchunks <= 0 || nchunks > 0x7fffffffL || rows_per_chunk <= 0 ||
+      nchunks != (M + rows_per_chunk - 1) / rows_per_chunk)
+    return EDRL_EINVAL;
+  if (group_ws && nchunks > 2 * FIN_GROUP) {
+    if (group_ws_bytes < edrl_bn_finalize_group_ws_bytes(nchunks, C)) return EDRL_ENOSPC;
+    const int G = (int)((nchunks + FIN_GROUP - 1) / FIN_GROUP);
+    hipLaunchKernelGGL(bn_group_kernel, dim3(edrl_cdiv(C, FIN_CH), G), dim3(256), 0, st, part, (int)nchunks, C, M,
+                       rows_per_chunk, group_ws);
+    EDRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(edrl_cdiv(C, 64)), dim3(64), 0, st, group_ws, G, C, M, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+    EDRL_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, part, (int)nchunks, C, M,
+                     rows_per_chunk, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale,
+                     shift);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

@@ -44,11 +44,17 @@ struct GatherGeom {
   int kh0, kw0, kstep, KHs, KWs;
   int Kfull;        // KH*KW*SC: row stride of the weight matrix
   int sshift;       // log2(stride) for DGRAD
+  // Fused BatchNorm statistics (GF_STATS, forward only): every workgroup emits the shifted moments of its 128 output
+  // rows, sum (y-K) and sum (y-K)^2 with K = the workgroup's first output row, into stat_part[tile_m][3][NC] (plane 2 = K) — the chunk
+  // partial layout of bn_pool.hip, so the BN statistics need no extra pass over the conv output.
+  float* stat_part;
+  const float* stat_shift;
 };
 
 #define GF_RELU 1
 #define GF_ACCUM 2
 #define GF_VEC_EPI 4   // set by the host when the float4 epilogue is legal (alignment, NC % 4 == 0)
+#define GF_STATS 8     // emit BatchNorm chunk partials from the vector epilogue
 
 template <int BM, int BN, bool DGRAD, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
@@ -462,6 +468,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const int n = n0 + wn0 + sc4 * 4;
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (bias && n < g.NC) bv4 = *reinterpret_cast<const f32x4*>(bias + n);
+    const bool stats = (g.flags & GF_STATS) != 0;
+    f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -470,6 +478,9 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
         for (int r = 0; r < 16; ++r)
           stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
       __syncthreads();
+      // shift K = the workgroup's first output row (always a valid row): it sits in row 0 of the staging region of
+      // the upper wave that owns this column half; a sample of the data, so var << mean^2 costs no precision.
+      if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(smem + (wave & 1) * 32 * SLD + sc4 * 4);
 #pragma unroll
       for (int t = 0; t < 32 / RPP2; ++t) {
         const int row = t * RPP2 + srow;
@@ -484,6 +495,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
             pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
           }
           f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SLD + sc4 * 4) + bv4;
+          if (stats) { const f32x4 d = v - kshift; st0 += d; st1 += d * d; }
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -495,6 +507,30 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
         }
       }
       __syncthreads();
+    }
+    if (stats) {
+      // lanes that share the channel group (same sc4) differ by multiples of C4: butterfly over those lane bits
+#pragma unroll
+      for (int o = 32; o >= C4; o >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
+      }
+      float* red = smem + 4 * 32 * SLD;          // beyond the staging regions: [wave][2][WN]
+      if (srow == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * WN + sc4 * 4 + e] = st0[e]; red[(wave * 2 + 1) * WN + sc4 * 4 + e] = st1[e]; }
+      }
+      __syncthreads();
+      if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {   // waves 0/1 own the column halves; add the lower row half (waves 2/3)
+        float* pp = g.stat_part + (long)tile_m * 3 * g.NC;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = sc4 * 4 + e;
+          pp[n + e] = red[(wave * 2 + 0) * WN + cc] + red[((wave + 2) * 2 + 0) * WN + cc];
+          pp[g.NC + n + e] = red[(wave * 2 + 1) * WN + cc] + red[((wave + 2) * 2 + 1) * WN + cc];
+          pp[2 * g.NC + n + e] = kshift[e];
+        }
+      }
     }
     return;
   }
@@ -903,7 +939,33 @@ int edrl_conv2d_nhwc_fwd_f32(const float* x, const float* w, const float* bias, 
   g.ld_src = ld_x; g.ld_dst = ld_y; g.ld_aux = ld_aux; g.flags = flags;
   g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
   g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
   return dispatch_gather<false>(x, w, y, bias, mul, g, st);
+}
+
+// Convolution forward with the BatchNorm statistics of its output fused into the epilogue.
+// stat_part: [chunks][3][Co] floats with chunks = ceil(N*Ho*Wo / 128) (edrl_conv_stats_chunks); stat_shift is unused
+// (reserved: the shift is taken from the data).
+// Requires the vector fast path (Ci % 16 == 0, Co % 4 == 0, 16-B aligned tensors): -22 otherwise.
+long edrl_conv_stats_chunks(int N, int Ho, int Wo) { return ((long)N * Ho * Wo + 127) / 128; }
+int edrl_conv2d_nhwc_fwd_stats_f32(const float* x, const float* w, float* y, const float* stat_shift, float* stat_part,
+                                   size_t stat_part_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                                   int KH, int KW, int stride, int pad, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+      pad < 0 || (Ci % 16) || (Co % 4) || !stat_part)
+    return EDRL_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return EDRL_EINVAL;
+  if ((long)N * Ho * Wo > 0x7fffffffL) return EDRL_EINVAL;
+  if (stat_part_bytes < (size_t)edrl_conv_stats_chunks(N, Ho, Wo) * 3 * Co * sizeof(float)) return EDRL_ENOSPC;
+  GatherGeom g;
+  g.M = (int)((long)N * Ho * Wo);
+  g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_src = Ci; g.ld_dst = Co; g.ld_aux = 0; g.flags = GF_STATS;
+  g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
+  g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
+  g.stat_part = stat_part; g.stat_shift = stat_shift;
+  return dispatch_gather<false>(x, w, y, nullptr, nullptr, g, st);
 }
 
 // Convolution data gradient: dx[n,hi,wi,ci] (+)= sum dy[n,ho,wo,co] * wt[ci,kh,kw,co]
@@ -923,6 +985,7 @@ int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int 
   g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Kfull = KH * KW * Co;
   g.ld_src = ld_dy; g.ld_dst = ld_dx; g.ld_aux = 0; g.flags = flags;
   g.step = stride; g.kstep = stride; g.sshift = sshift;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
   // one launch per parity class (ph, pw) = ((hi+pad) % s, (wi+pad) % s): only the taps kh = ph (mod s) reach it
   for (int ph = 0; ph < stride; ++ph)
     for (int pw = 0; pw < stride; ++pw) {

@@ -59,6 +59,34 @@ def _bn_fwd(raw, bn, relu, residual=None):
     return out, mean, rstd, mask
 
 
+_FUSE_STATS = os.environ.get("EDRL_FUSE_BN_STATS", "1") != "0"
+
+
+def _conv_bn_fwd(inp, w, bn, stride, pad, relu, residual=None):
+    """conv -> train-mode BN (-> +residual) (-> ReLU).  When the vector fast path applies (Ci % 16 == 0) the BN
+    statistics come out of the conv epilogue (no extra pass over the conv output).  -> (raw, out, mean, rstd, mask)."""
+    if not (_FUSE_STATS and inp.shape[-1] % 16 == 0 and w.shape[0] % 4 == 0):
+        raw = ops.conv2d_fwd(inp, w, stride=stride, pad=pad)
+        out, mean, rstd, mask = _bn_fwd(raw, bn, relu, residual)
+        return raw, out, mean, rstd, mask
+    raw, part, chunks = ops.conv2d_fwd_stats(inp, w, bn["running_mean"], stride, pad)
+    C = raw.shape[-1]
+    M = raw.numel() // C
+    dev = raw.device
+    mean = torch.empty(C, device=dev, dtype=torch.float32)
+    rstd = torch.empty_like(mean); scale = torch.empty_like(mean); shift = torch.empty_like(mean)
+    gbytes = L.query("edrl_bn_finalize_group_ws_bytes", chunks, C)
+    gws = torch.empty(gbytes // 8, device=dev, dtype=torch.float64)
+    L.call("edrl_bn_finalize_partials_f32", P(part), chunks, 128, M, C, P(bn["weight"]), P(bn["bias"]),
+           P(bn["running_mean"]), P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(mean), P(rstd),
+           P(scale), P(shift), P(gws), gbytes)
+    out = torch.empty_like(raw)
+    mask = torch.empty((M, C // 4), device=dev, dtype=torch.uint8) if relu else None
+    L.call("edrl_bn_apply_f32", P(raw), P(mean), P(scale), P(shift), P(residual), P(out), P(mask), M, C, C,
+           1 if relu else 0)
+    return raw, out, mean, rstd, mask
+
+
 def _bn_bwd(dout, mask, raw, mean, rstd, gamma, want_dres):
     """-> (d_raw, dgamma, dbeta, dres). `mask` = the ReLU sign-bit bytes written by _bn_fwd (None: no ReLU)."""
     C = raw.shape[-1]
@@ -85,11 +113,10 @@ class _TrunkFn(torch.autograd.Function):
         saved = {}
         x = ops._chk(x, "encoder input")
 
-        def conv(name, inp, stride, pad):
-            return ops.conv2d_fwd(inp, p[name + ".weight"], stride=stride, pad=pad)
+        def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
+            return _conv_bn_fwd(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
 
-        raw = conv("conv1", x, 2, 3)
-        a0, m0, r0, k0 = _bn_fwd(raw, bnd("bn1", p), True)
+        raw, a0, m0, r0, k0 = cb("conv1", "bn1", x, 2, 3, True)
         N, H, W, C = a0.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         p0 = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
@@ -100,27 +127,20 @@ class _TrunkFn(torch.autograd.Function):
         for blk in T.blocks:
             pre, s = blk["name"], blk["stride"]
             rec = {"x": cur}
-            if T.kind == "bottleneck":
-                c1 = conv(pre + ".conv1", cur, 1, 0)
-                a1, m1, r1, k1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
-                c2 = conv(pre + ".conv2", a1, s, 1)
-                a2, m2, r2, k2 = _bn_fwd(c2, bnd(pre + ".bn2", p), True)
-                c3 = conv(pre + ".conv3", a2, 1, 0)
-                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2, a2=a2, s2=(m2, r2), k2=k2, c3=c3)
-                last, last_bn = c3, pre + ".bn3"
-            else:
-                c1 = conv(pre + ".conv1", cur, s, 1)
-                a1, m1, r1, k1 = _bn_fwd(c1, bnd(pre + ".bn1", p), True)
-                c2 = conv(pre + ".conv2", a1, 1, 1)
-                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2)
-                last, last_bn = c2, pre + ".bn2"
             if blk["downsample"]:
-                cd = conv(pre + ".downsample.0", cur, s, 0)
-                idn, md, rd, _ = _bn_fwd(cd, bnd(pre + ".downsample.1", p), False)
+                cd, idn, md, rd, _ = cb(pre + ".downsample.0", pre + ".downsample.1", cur, s, 0, False)
                 rec.update(cd=cd, sd=(md, rd))
             else:
                 idn = cur
-            out, ml, rl, kl = _bn_fwd(last, bnd(last_bn, p), True, residual=idn)
+            if T.kind == "bottleneck":
+                c1, a1, m1, r1, k1 = cb(pre + ".conv1", pre + ".bn1", cur, 1, 0, True)
+                c2, a2, m2, r2, k2 = cb(pre + ".conv2", pre + ".bn2", a1, s, 1, True)
+                c3, out, ml, rl, kl = cb(pre + ".conv3", pre + ".bn3", a2, 1, 0, True, residual=idn)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2, a2=a2, s2=(m2, r2), k2=k2, c3=c3)
+            else:
+                c1, a1, m1, r1, k1 = cb(pre + ".conv1", pre + ".bn1", cur, s, 1, True)
+                c2, out, ml, rl, kl = cb(pre + ".conv2", pre + ".bn2", a1, 1, 1, True, residual=idn)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2)
             rec.update(sl=(ml, rl), kl=kl)
             saved[pre] = rec
             cur = out

@@ -104,6 +104,21 @@ def conv2d_fwd(x, w, bias=None, mul=None, stride=1, pad=0, relu=False, out=None,
     return out
 
 
+def conv2d_fwd_stats(x, w, stat_shift, stride=1, pad=0):
+    """Conv forward with the BatchNorm chunk partials of its output produced by the epilogue.
+    -> (y [N,Ho,Wo,Co], part [chunks][3][Co], chunks).  Needs Ci % 16 == 0."""
+    N, Hi, Wi, Ci = x.shape
+    Co, KH, KW, _ = w.shape
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    out = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.float32)
+    chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
+    part = torch.empty((chunks, 3, Co), device=x.device, dtype=torch.float32)
+    _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_stats_f32", P(x), P(w), P(out),
+                  P(stat_shift), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)
+    return out, part, chunks
+
+
 def permute_weight(w):
     """[Co,KH,KW,Ci] -> [Ci,KH,KW,Co] (or [out,in] -> [in,out])."""
     if w.dim() == 2:

@@ -355,3 +355,29 @@ def test_linear_odd_widths(edrl, dev):
         yg.backward(gy.to(dev))
         check(f"lin{(rows, cin, cout)}", yg.cpu(), y, 2e-5)
         check("dx", xg.grad.cpu(), xd.grad, 2e-5); check("dw", wg.grad.cpu(), wd.grad, 2e-5); check("db", bg.grad.cpu(), bd.grad, 2e-5)
+
+
+@pytest.mark.parametrize("case", [(3, 64, 20, 18, 128, 3, 1, 1), (2, 32, 9, 9, 64, 1, 1, 0), (5, 16, 13, 11, 200, 3, 2, 1),
+                                  (40, 16, 56, 56, 64, 1, 1, 0)])   # last: 980 chunks -> two-stage finalize
+def test_conv_fused_bn_statistics(edrl, dev, case):
+    """The conv epilogue's chunk partials (shifted moments) must give the same batch statistics as a pass over the output."""
+    L = edrl._lib
+    N, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(13)
+    x = (torch.randn(N, H, W, Ci, generator=g) + 0.7).to(dev)
+    w = (torch.randn(Co, k, k, Ci, generator=g) * 0.1).to(dev)
+    shift = torch.randn(Co, generator=g).to(dev)
+    y_ref = edrl.ops.conv2d_fwd(x, w, stride=s, pad=p)
+    y, part, chunks = edrl.ops.conv2d_fwd_stats(x, w, shift, s, p)
+    assert torch.equal(y, y_ref), "fused-statistics epilogue must not change the conv output"
+    M = y.numel() // Co
+    outs = [torch.empty(Co, device=dev) for _ in range(4)]
+    rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
+    gbytes = L.query("edrl_bn_finalize_group_ws_bytes", chunks, Co)
+    gws = torch.empty(gbytes // 8, device=dev, dtype=torch.float64)
+    L.call("edrl_bn_finalize_partials_f32", L.ptr(part), chunks, 128, M, Co, None, None, L.ptr(rm), L.ptr(rv), 0.1, 1e-5,
+           L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(outs[3]), L.ptr(gws), gbytes)
+    yd = y.double().view(M, Co).cpu()
+    check(f"fused_mean{case}", outs[0].cpu(), yd.mean(0), 1e-5)
+    check(f"fused_rstd{case}", outs[1].cpu(), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-5)
+    check("fused_running_var", rv.cpu(), 0.9 + 0.1 * yd.var(0, unbiased=True), 1e-5)
