@@ -422,6 +422,78 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
   }
 }
 
+// float4 / 4-byte-index variants (C % 4 == 0): 16 B per lane instead of 4
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  unsigned char* __restrict__ idx, int N, int H, int W,
+                                                                  int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool any = false;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = ho * 2 - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = wo * 2 - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + h) * W + w) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (!any || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
+        any = true;
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = best;
+    *reinterpret_cast<unsigned int*>(idx + i * 4) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+  }
+}
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v4_kernel(const float* __restrict__ dy,
+                                                                  const unsigned char* __restrict__ idx,
+                                                                  float* __restrict__ dx, int N, int H, int W, int C,
+                                                                  int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long total = (long)N * H * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int th = h + 1 - kh;
+      if (th < 0 || (th & 1)) continue;
+      const int ho = th >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tw = w + 1 - kw;
+        if (tw < 0 || (tw & 1)) continue;
+        const int wo = tw >> 1;
+        if (wo >= Wo) continue;
+        const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
+        const unsigned m = *reinterpret_cast<const unsigned int*>(idx + o);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const unsigned tap = (unsigned)(kh * 3 + kw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (((m >> (8 * e)) & 0xff) == tap) s[e] += g[e];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = s;
+  }
+}
+
 // [N][C][H][W] -> [N][H][W][Cp] (channels >= C zero filled)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            int N, int C, int H, int W, int Cp) {
@@ -561,8 +633,12 @@ int edrl_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int 
                               hipStream_t st) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, idx, N,
-                     H, W, C, Ho, Wo);
+  if ((C & 3) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)idx) & 15) == 0)
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_v4_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, y, idx,
+                       N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, idx, N,
+                       H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
@@ -570,8 +646,12 @@ int edrl_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* 
                               hipStream_t st) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, st, dy, idx, dx, N,
-                     H, W, C, Ho, Wo);
+  if ((C & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)idx) & 15) == 0)
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_v4_kernel, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, st, dy, idx, dx,
+                       N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, st, dy, idx, dx, N,
+                       H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

@@ -22,6 +22,12 @@ from . import ops
 from .encoders import FundusEncoder, OCTSliceEncoder
 
 
+import os
+
+# EDRL_FUNDUS_STREAM=1: run the fundus encoder on a side stream concurrently with the OCT encoder (opt-in).
+_FUNDUS_SIDE_STREAM = os.environ.get("EDRL_FUNDUS_STREAM", "0") == "1"
+
+
 def off_diagonal(x):
     """Flattened view of the off-diagonal elements of a square matrix (fusion_net.py:544-548)."""
     n, m = x.shape
@@ -341,6 +347,20 @@ class MedFusion(nn.Module):
 
     def forward(self, X, y, epoch=None, noise=None):
         self.check_labels(y)
-        x, _fundus_out = self.transformer_2DNet(X[0])
-        x1, _oct_out = self.transformer_3DNet(X[1])
+        if _FUNDUS_SIDE_STREAM and X[0].is_cuda:
+            # The two encoders are independent until the head: the small fundus pass (B images) runs on a side stream
+            # beside the OCT pass (B*S images); autograd replays the same streams in backward.
+            main = torch.cuda.current_stream()
+            side = getattr(self, "_fundus_stream", None)
+            if side is None:
+                side = self._fundus_stream = torch.cuda.Stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                x, _fundus_out = self.transformer_2DNet(X[0])
+            x1, _oct_out = self.transformer_3DNet(X[1])
+            main.wait_stream(side)
+            x.record_stream(main)
+        else:
+            x, _fundus_out = self.transformer_2DNet(X[0])
+            x1, _oct_out = self.transformer_3DNet(X[1])
         return self.forward_tokens(x, x1, y, noise)

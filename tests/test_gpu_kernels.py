@@ -130,10 +130,11 @@ def test_batchnorm_train(edrl, dev, M, C):
     check("bn_dres", dres.view(M, C).cpu(), rd.grad, 1e-6)
 
 
-def test_maxpool_and_layout(edrl, dev):
+@pytest.mark.parametrize("C", [64, 6])
+def test_maxpool_and_layout(edrl, dev, C):
     L = edrl._lib
     g = torch.Generator().manual_seed(5)
-    N, C, H, W = 2, 64, 17, 20
+    N, H, W = 2, 17, 20
     x = torch.randn(N, C, H, W, generator=g)
     xd = x.double().requires_grad_(True)
     y = F.max_pool2d(xd, 3, 2, 1)
