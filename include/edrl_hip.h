@@ -69,6 +69,20 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
 /* in [A][B][C] -> out [C][B][A]. */
 int edrl_permute_weight_f32(const float* in, float* out, int A, int B, int C, hipStream_t stream);
 
+/* ---- bf16 contractions (conv_bf16.hip): the C2/C4 precision of SURVEY.md §8(a) rows E1/E2 ------------------------
+ * bf16 operands (device pointers to IEEE bfloat16), fp32 accumulate on v_mfma_f32_32x32x16_bf16, bf16 results.
+ * Forward: Ci % 32 == 0, Co % 4 == 0; stat_part (optional) receives the fp32 BatchNorm chunk partials of the
+ * accumulators exactly as edrl_conv2d_nhwc_fwd_stats_f32.  Data gradient: Co % 32 == 0, Ci % 4 == 0, wt = bf16
+ * [Ci,KH,KW,Co] (edrl_permute_weight_bf16), flags = EDRL_FLAG_ACCUM or 0. */
+int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat_part, size_t stat_part_bytes, int N,
+                              int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                              hipStream_t stream);
+int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
+                                int Co, int KH, int KW, int stride, int pad, int flags, hipStream_t stream);
+int edrl_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t stream);
+int edrl_cast_bf16_to_f32(const void* in, float* out, long n, hipStream_t stream);
+int edrl_permute_weight_bf16(const float* in, void* out, int A, int B, int C, hipStream_t stream);
+
 /* ---- BatchNorm / pooling / layout (bn_pool.hip) -----------------------------------------
  * Train-mode BatchNorm over rows of x [M][C]: batch statistics, running-stat update
  * (momentum, unbiased variance), and the per-channel affine (scale, shift) that applies it.

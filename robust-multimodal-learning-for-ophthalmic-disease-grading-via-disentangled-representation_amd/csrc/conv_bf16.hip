@@ -1,0 +1,375 @@
+// bf16 implicit-GEMM convolution (forward / data gradient) on the gfx950 bf16 matrix cores — the C2/C4 precision
+// of SURVEY.md §8(a) rows E1/E2: bf16 operands, fp32 accumulate, fp32 BatchNorm statistics taken from the accumulators.
+//
+// Same contraction and tiling as conv_gemm.hip's fast path: D[m][n] = sum_k Agather[m][k] * Wm[n][k], M = output
+// pixels (NHWC rows), N = Cout, K = (kh,kw,c); 256 threads = 2x2 waves, wave tile 64x64 of 32x32 MFMA tiles
+// (v_mfma_f32_32x32x16_bf16: lane (r = l&31, h = l>>5) supplies A[r][8h..8h+7] / B[8h..8h+7][r] as ONE 16-byte
+// fragment), K tile 32 bf16 = 64 B per row, staged to LDS as [row][32+8] (80-B rows: ds_read_b128 conflict-free),
+// double buffered, 40 KiB per workgroup -> 3 workgroups per CU.  The source channel count must be a multiple of 32
+// (a K tile never straddles a tap), which holds for every conv of the ResNet trunks except the stem; the stem and
+// the weight gradient stay on the fp32 kernels (conv_gemm.hip) in round 1.
+#include "edrl_common.h"
+#include "conv_geom.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define HBK 32            // K tile in bf16 elements
+#define HLD (HBK + 8)     // padded LDS row (elements): 80 bytes
+
+template <int BN, bool DGRAD>
+__global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* __restrict__ src,
+                                                                  const __bf16* __restrict__ wm,
+                                                                  __bf16* __restrict__ dst, GatherGeom g, int tiles_n) {
+  constexpr int BM = 128;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_LD = BM / 64, B_LD = BN / 64;   // 16-byte loads per thread per K tile (64 rows per pass)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);      // [2][BM][HLD]
+  __bf16* Bs = As + 2 * BM * HLD;                        // [2][BN][HLD]
+  float* smem = reinterpret_cast<float*>(smem_raw);      // epilogue staging view
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int lid = edrl_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int k8 = (tid & 3) * 8;
+  const int r0 = tid >> 2;
+  int rn[A_LD], rh[A_LD], rw[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const long m = m0 + r0 + 64 * i;
+    if (m < g.M) {
+      const int ohw = g.OHs * g.OWs;
+      const int n = (int)(m / ohw);
+      const int rem = (int)(m - (long)n * ohw);
+      const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+      const int oh = g.h0 + ii * g.step, ow = g.w0 + jj * g.step;
+      rn[i] = n;
+      if (DGRAD) { rh[i] = oh + g.pad; rw[i] = ow + g.pad; }
+      else       { rh[i] = oh * g.stride - g.pad; rw[i] = ow * g.stride - g.pad; }
+    } else { rn[i] = -1; rh[i] = 0; rw[i] = 0; }
+  }
+  long wrow[B_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int n = n0 + r0 + 64 * i;
+    wrow[i] = n < g.NC ? (long)n * g.Kfull : -1;
+  }
+
+  int c = k8, ta = 0, tb = 0, kk = k8;
+  long rowoff[A_LD];
+  long tapoff = 0;
+  auto retap = [&]() {
+    const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
+    tapoff = (long)(kh * g.KW + kw) * g.SC;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      int sh, sw;
+      bool ok = rn[i] >= 0;
+      if (DGRAD) {
+        const int th = rh[i] - kh, tw = rw[i] - kw;
+        ok = ok && th >= 0 && tw >= 0;
+        sh = th >> g.sshift; sw = tw >> g.sshift;
+      } else { sh = rh[i] + kh; sw = rw[i] + kw; }
+      ok = ok && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+      rowoff[i] = ok ? (((long)rn[i] * g.SH + sh) * g.SW + sw) * g.ld_src : -1;
+    }
+  };
+  retap();
+  auto advance = [&]() {
+    c += HBK; kk += HBK;
+    if (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
+  };
+
+  bf16x8 a_st[A_LD], b_st[B_LD];
+  bool a_ok[A_LD], b_ok[B_LD];
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
+  auto load_tile = [&]() {
+    const bool kvalid = kk < g.Ktot;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const bool ok = kvalid && rowoff[i] >= 0;
+      a_ok[i] = ok;
+      a_st[i] = *reinterpret_cast<const bf16x8*>(src + (ok ? rowoff[i] + c : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const bool ok = kvalid && wrow[i] >= 0;
+      b_ok[i] = ok;
+      b_st[i] = *reinterpret_cast<const bf16x8*>(wm + (ok ? wrow[i] + tapoff + c : 0));
+    }
+  };
+  auto store_tile = [&](int buf) {
+    __bf16* a = As + buf * BM * HLD;
+    __bf16* b = Bs + buf * BN * HLD;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<bf16x8*>(a + (r0 + 64 * i) * HLD + k8) = a_ok[i] ? a_st[i] : zero8;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<bf16x8*>(b + (r0 + 64 * i) * HLD + k8) = b_ok[i] ? b_st[i] : zero8;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = (g.Ktot + HBK - 1) / HBK;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    advance();
+    load_tile();                          // next tile's loads first; consumed after the MFMA chain
+    __builtin_amdgcn_sched_barrier(0);
+    const __bf16* a = As + buf * BM * HLD + (wm0 + li) * HLD + 8 * lh;
+    const __bf16* b = Bs + buf * BN * HLD + (wn0 + li) * HLD + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < HBK / 16; ++s) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * HLD + s * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * HLD + s * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- vector epilogue through LDS (fp32 staging): lane owns 4 consecutive channels of one pixel -> 8-byte bf16 store
+  const bool accum = g.flags & GF_ACCUM;
+  const bool stats = (g.flags & GF_STATS) != 0;
+  constexpr int SLD = WN + 4;
+  constexpr int C4 = WN / 4;
+  constexpr int RPP2 = 64 / C4;
+  float* stage = smem + wave * 32 * SLD;
+  const int srow = lane / C4, sc4 = lane % C4;
+  const int n = n0 + wn0 + sc4 * 4;
+  f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
+    __syncthreads();
+    if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(smem + (wave & 1) * 32 * SLD + sc4 * 4);
+#pragma unroll
+    for (int t = 0; t < 32 / RPP2; ++t) {
+      const int row = t * RPP2 + srow;
+      const long m = m0 + wm0 + i * 32 + row;
+      if (m < g.M && n < g.NC) {
+        long pix = m;
+        if (DGRAD && g.step > 1) {
+          const int ohw = g.OHs * g.OWs;
+          const int nn = (int)(m / ohw);
+          const int rem = (int)(m - (long)nn * ohw);
+          const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+          pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SLD + sc4 * 4);
+        if (stats) { const f32x4 d = v - kshift; st0 += d; st1 += d * d; }
+        __bf16* p = dst + pix * g.ld_dst + n;
+        if (accum) {
+          const bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
+        }
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x4*>(p) = ov;
+      }
+    }
+    __syncthreads();
+  }
+  if (stats) {
+#pragma unroll
+    for (int o = 32; o >= C4; o >>= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
+    }
+    float* red = smem + 4 * 32 * SLD;
+    if (srow == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * WN + sc4 * 4 + e] = st0[e]; red[(wave * 2 + 1) * WN + sc4 * 4 + e] = st1[e]; }
+    }
+    __syncthreads();
+    if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
+      float* pp = g.stat_part + (long)tile_m * 3 * g.NC;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = sc4 * 4 + e;
+        pp[n + e] = red[(wave * 2 + 0) * WN + cc] + red[((wave + 2) * 2 + 0) * WN + cc];
+        pp[g.NC + n + e] = red[(wave * 2 + 1) * WN + cc] + red[((wave + 2) * 2 + 1) * WN + cc];
+        pp[2 * g.NC + n + e] = kshift[e];
+      }
+    }
+  }
+}
+
+template <int BN, bool DGRAD>
+static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st) {
+  const int tiles_m = edrl_cdiv(g.M, 128), tiles_n = edrl_cdiv(g.NC, BN);
+  const long nblk = (long)tiles_m * tiles_n;
+  if (nblk <= 0) return 0;
+  if (nblk > 0x7fffffffL) return EDRL_EINVAL;
+  size_t lds = (size_t)2 * (128 + BN) * HLD * sizeof(__bf16);
+  const size_t epi = (size_t)(4 * 32 * (BN / 2 + 4) + 4 * 2 * (BN / 2)) * sizeof(float);
+  if (epi > lds) lds = epi;
+  auto kern = conv_gather_bf16_kernel<BN, DGRAD>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, g, tiles_n);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// fp32 -> bf16 (round to nearest even), 4 elements per lane
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+      *reinterpret_cast<bf16x4*>(out + i) = o;
+    } else {
+      for (long k = i; k < n; ++k) out[k] = (__bf16)in[k];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const __bf16* __restrict__ in, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+// in fp32 [A][B][C] -> out bf16 [C][B][A]
+__global__ void permute_021_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int A, int B, int C) {
+  const long n = (long)A * B * C;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = (int)(i % A);
+  const long t = i / A;
+  const int b = (int)(t % B);
+  const int c = (int)(t / B);
+  out[i] = (__bf16)in[((long)a * B + b) * C + c];
+}
+
+static inline int cast_grid(long n) {
+  long b = (n / 4 + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" {
+
+// y (bf16) = conv(x (bf16), w (bf16 [Co,KH,KW,Ci])), optional fused BatchNorm chunk partials (fp32, from the accumulators).
+int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat_part, size_t stat_part_bytes, int N,
+                              int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                              hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+      pad < 0 || (Ci % HBK) || (Co % 4))
+    return EDRL_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 7)) return EDRL_EINVAL;
+  if ((long)N * Ho * Wo > 0x7fffffffL) return EDRL_EINVAL;
+  GatherGeom g;
+  g.M = (int)((long)N * Ho * Wo);
+  g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_src = Ci; g.ld_dst = Co; g.ld_aux = 0; g.flags = 0;
+  g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
+  g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
+  if (stat_part) {
+    if (stat_part_bytes < (size_t)(((long)g.M + 127) / 128) * 3 * Co * sizeof(float)) return EDRL_ENOSPC;
+    g.flags |= GF_STATS;
+    g.stat_part = stat_part;
+  }
+  if (Co <= 64) return launch_gather_bf16<64, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
+  return launch_gather_bf16<128, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
+}
+
+// dx (bf16) [+]= conv_transpose(dy (bf16), wt (bf16 [Ci,KH,KW,Co])): parity-class decomposition as in the fp32 kernel
+int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
+                                int Co, int KH, int KW, int stride, int pad, int flags, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || (Co % HBK) ||
+      (Ci % 4))
+    return EDRL_EINVAL;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)wt & 15) || ((uintptr_t)dx & 7)) return EDRL_EINVAL;
+  if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
+  int sshift = 0;
+  while ((1 << sshift) < stride) ++sshift;
+  if ((1 << sshift) != stride) return EDRL_EINVAL;
+  GatherGeom g;
+  g.OH = Hi; g.OW = Wi; g.NC = Ci; g.SH = Ho; g.SW = Wo; g.SC = Co;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Kfull = KH * KW * Co;
+  g.ld_src = Co; g.ld_dst = Ci; g.ld_aux = 0; g.flags = flags & GF_ACCUM;
+  g.step = stride; g.kstep = stride; g.sshift = sshift;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      g.h0 = ((ph - pad) % stride + stride) % stride;
+      g.w0 = ((pw - pad) % stride + stride) % stride;
+      g.OHs = g.h0 < Hi ? (Hi - g.h0 + stride - 1) / stride : 0;
+      g.OWs = g.w0 < Wi ? (Wi - g.w0 + stride - 1) / stride : 0;
+      if (g.OHs == 0 || g.OWs == 0) continue;
+      g.kh0 = ph; g.kw0 = pw;
+      g.KHs = ph < KH ? (KH - ph + stride - 1) / stride : 0;
+      g.KWs = pw < KW ? (KW - pw + stride - 1) / stride : 0;
+      g.Ktot = g.KHs * g.KWs * Co;
+      if (g.Ktot == 0 && (flags & GF_ACCUM)) continue;
+      g.M = (int)((long)N * g.OHs * g.OWs);
+      const int rc = Ci <= 64 ? launch_gather_bf16<64, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st)
+                              : launch_gather_bf16<128, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+int edrl_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t st) {
+  if (n <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cast_grid(n)), dim3(256), 0, st, in, (__bf16*)out, n);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_cast_bf16_to_f32(const void* in, float* out, long n, hipStream_t st) {
+  if (n <= 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(cast_grid(n * 4)), dim3(256), 0, st, (const __bf16*)in, out, n);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+// in fp32 [A][B][C] -> out bf16 [C][B][A]   (forward weight -> data-gradient weight, cast on the way)
+int edrl_permute_weight_bf16(const float* in, void* out, int A, int B, int C, hipStream_t st) {
+  if (A <= 0 || B <= 0 || C <= 0) return EDRL_EINVAL;
+  const long n = (long)A * B * C;
+  hipLaunchKernelGGL(permute_021_bf16_kernel, dim3(edrl_cdiv(n, 256)), dim3(256), 0, st, in, (__bf16*)out, A, B, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

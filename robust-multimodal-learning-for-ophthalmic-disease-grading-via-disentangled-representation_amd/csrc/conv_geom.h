@@ -1,0 +1,33 @@
+// Geometry of the implicit-GEMM "gather" contraction shared by the fp32 and bf16 conv kernels.
+#pragma once
+
+struct GatherGeom {
+  int M;            // destination rows = N*OH*OW
+  int OH, OW;       // destination spatial
+  int NC;           // destination channels (GEMM N)
+  int SH, SW, SC;   // source spatial / channels
+  int KH, KW, stride, pad;
+  int Ktot;         // KH*KW*SC
+  long ld_src;      // source pixel stride (elements)
+  long ld_dst;      // destination pixel stride (elements)
+  long ld_aux;      // pixel stride of `mul` / `addend` operands (elements)
+  int flags;        // bit0 relu, bit1 accumulate into dst
+  // Sub-lattice ("parity class") view used by the strided data gradient: rows enumerate the
+  // destination pixels (h0 + i*step, w0 + j*step), i < OHs, j < OWs, and K runs over the taps
+  // (kh0 + a*kstep, kw0 + b*kstep), a < KHs, b < KWs — exactly the taps that hit that class, so no
+  // MFMA work is spent on masked taps.  The plain case is step = kstep = 1, h0 = w0 = kh0 = kw0 = 0.
+  int h0, w0, step, OHs, OWs;
+  int kh0, kw0, kstep, KHs, KWs;
+  int Kfull;        // KH*KW*SC: row stride of the weight matrix
+  int sshift;       // log2(stride) for DGRAD
+  // Fused BatchNorm statistics (GF_STATS, forward only): every workgroup emits the shifted moments of its 128 output
+  // rows, sum (y-K) and sum (y-K)^2 with K = the workgroup's first output row, into stat_part[tile_m][3][NC] (plane 2 = K) — the chunk
+  // partial layout of bn_pool.hip, so the BN statistics need no extra pass over the conv output.
+  float* stat_part;
+  const float* stat_shift;
+};
+
+#define GF_RELU 1
+#define GF_ACCUM 2
+#define GF_VEC_EPI 4   // set by the host when the float4 epilogue is legal (alignment, NC % 4 == 0)
+#define GF_STATS 8     // emit BatchNorm chunk partials from the vector epilogue

@@ -813,3 +813,53 @@ def twin_view(x, sigma=0.5, noise=None):
     out = torch.empty_like(x)
     L.call("edrl_twin_view_f32", P(x), P(noise), P(out), x.numel(), float(sigma))
     return out
+
+
+# ------------------------------------------------------------------ bf16 contractions (C2/C4 precision; raw helpers)
+def to_bf16(x):
+    x = _chk(x, "to_bf16.x", False).contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    L.call("edrl_cast_f32_to_bf16", P(x), P(out), x.numel())
+    return out
+
+
+def to_f32(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    L.call("edrl_cast_bf16_to_f32", P(x), P(out), x.numel())
+    return out
+
+
+def permute_weight_bf16(w):
+    """fp32 [Co,KH,KW,Ci] -> bf16 [Ci,KH,KW,Co]."""
+    A, B, C = w.shape[0], w.shape[1] * w.shape[2], w.shape[3]
+    out = torch.empty((C, w.shape[1], w.shape[2], A), device=w.device, dtype=torch.bfloat16)
+    L.call("edrl_permute_weight_bf16", P(w), P(out), A, B, C)
+    return out
+
+
+def conv2d_fwd_bf16(x, w, stride=1, pad=0, stats=False):
+    """x bf16 [N,Hi,Wi,Ci], w bf16 [Co,KH,KW,Ci] -> y bf16 (, part fp32 [chunks][3][Co], chunks)."""
+    N, Hi, Wi, Ci = x.shape
+    Co, KH, KW, _ = w.shape
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    out = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.bfloat16)
+    part, chunks = None, 0
+    if stats:
+        chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
+        part = torch.empty((chunks, 3, Co), device=x.device, dtype=torch.float32)
+    _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_bf16", P(x), P(w), P(out),
+                  P(part), part.numel() * 4 if stats else 0, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)
+    return (out, part, chunks) if stats else out
+
+
+def conv2d_dgrad_bf16(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=False):
+    N, Hi, Wi, Ci = x_shape
+    _, Ho, Wo, Co = dy.shape
+    KH, KW = wt.shape[1], wt.shape[2]
+    if out is None:
+        out = torch.empty((N, Hi, Wi, Ci), device=dy.device, dtype=torch.bfloat16)
+    _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bf16", P(dy), P(wt),
+                  P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0)
+    return out
