@@ -79,6 +79,12 @@ int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat
                               hipStream_t stream);
 int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
                                 int Co, int KH, int KW, int stride, int pad, int flags, hipStream_t stream);
+/* Weight gradient: dw fp32 [Co,KH,KW,Ci] [+]= sum_pix dy(bf16) (x) x(bf16); transposing LDS reads (ds_read_b64_tr_b16),
+ * split-K with ordered reduction.  Co % 8 == 0, Ci % 8 == 0. */
+size_t edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW);
+int edrl_conv2d_nhwc_wgrad_bf16(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_bytes, int N,
+                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                int accumulate, hipStream_t stream);
 int edrl_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t stream);
 int edrl_cast_bf16_to_f32(const void* in, float* out, long n, hipStream_t stream);
 int edrl_permute_weight_bf16(const float* in, void* out, int A, int B, int C, hipStream_t stream);

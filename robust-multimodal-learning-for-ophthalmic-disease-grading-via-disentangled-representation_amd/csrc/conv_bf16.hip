@@ -250,6 +250,203 @@ static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ weight gradient (bf16)
+// dW[co][kcol] (fp32) = sum_pixels dY[pix][co] * Xcol[pix][kcol], kcol = (tap, ci): the reduction runs over PIXELS, the
+// slow axis of both NHWC operands, while the bf16 MFMA wants 8 consecutive k per lane.  Both tiles are therefore
+// staged in their natural [pixel][channel] image (16-byte global loads, channels contiguous) and the fragments are
+// fetched with the gfx950 transposing LDS read ds_read_b64_tr_b16 (a 4-pixel x 16-channel block, delivered
+// column-major: lane i of a 16-lane group gets channel i of the 4 pixels) — two reads per 8-deep fragment, no scatter.
+// Row pitch = BM*2 + 64 bytes puts the 4 rows of a block and the two blocks of a 32-lane half on disjoint banks.
+// Split-K over pixels with fp32 partial slabs reduced in fixed order (deterministic), as in the fp32 kernel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define WBK 32   // pixels per K tile
+
+struct WgradGeomH {
+  long P;
+  int OH, OW, Co, SH, SW, SC, KH, KW, stride, pad, Ktot;
+  int tiles_per_split;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int pitch, int pix0, int col0, int lane) {
+  // block rows pix0..pix0+3 (and +4..+7), columns col0..col0+15; lane 4q+p of the 16-lane group addresses row q, cols 4p..4p+3
+  const int g16 = lane & 15, q = g16 >> 2, p4 = g16 & 3;
+  const __bf16* a0 = base + (pix0 + q) * pitch + col0 + 4 * p4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * pitch));
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
+                                                                 float* __restrict__ part, WgradGeomH g) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int PA = BM + 32, PB = BN + 32;          // LDS row pitch in elements (+64 bytes)
+  constexpr int AC8 = BM / 8, BC8 = BN / 8;          // 16-byte chunks per pixel row
+  constexpr int A_LD = (WBK * AC8) / 256, B_LD = (WBK * BC8) / 256;
+  static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for 256 threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);   // [2][WBK][PA]
+  __bf16* Bs = As + 2 * WBK * PA;                     // [2][WBK][PB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int co0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long ptiles = (g.P + WBK - 1) / WBK;
+  const long t_begin = (long)blockIdx.z * g.tiles_per_split;
+  long t_end = t_begin + g.tiles_per_split;
+  if (t_end > ptiles) t_end = ptiles;
+
+  // staging coordinates: chunk (8 channels) fixed per thread, pixel rows advance by WBK per tile
+  const int ac8 = tid % AC8, bc8 = tid % BC8;
+  const int kcol = n0 + bc8 * 8;
+  const bool kvalid = kcol < g.Ktot;
+  int kkh = 0, kkw = 0, kc = 0;
+  if (kvalid) { const int tap = kcol / g.SC; kc = kcol - tap * g.SC; kkh = tap / g.KW; kkw = tap - kkh * g.KW; }
+  const int ohw = g.OH * g.OW;
+  int bn_[B_LD], boh[B_LD], bow[B_LD];
+  long bp[B_LD], ap[A_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const long p = t_begin * WBK + (tid + 256 * i) / BC8;
+    bp[i] = p;
+    const long n = p / ohw;
+    const int rem = (int)(p - n * ohw);
+    bn_[i] = (int)n; boh[i] = rem / g.OW; bow[i] = rem - boh[i] * g.OW;
+  }
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) ap[i] = t_begin * WBK + (tid + 256 * i) / AC8;
+
+  bf16x8 a_st[A_LD], b_st[B_LD];
+  bool a_ok[A_LD], b_ok[B_LD];
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
+  auto load_tile = [&]() {
+    const int co = co0 + ac8 * 8;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const bool ok = ap[i] < g.P && co < g.Co;
+      a_ok[i] = ok;
+      a_st[i] = *reinterpret_cast<const bf16x8*>(dy + (ok ? ap[i] * g.Co + co : 0));
+      ap[i] += WBK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int sh = boh[i] * g.stride - g.pad + kkh, sw = bow[i] * g.stride - g.pad + kkw;
+      const bool ok = kvalid && bp[i] < g.P && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+      b_ok[i] = ok;
+      b_st[i] = *reinterpret_cast<const bf16x8*>(x + (ok ? (((long)bn_[i] * g.SH + sh) * g.SW + sw) * g.SC + kc : 0));
+      bp[i] += WBK; bow[i] += WBK;
+      while (bow[i] >= g.OW) { bow[i] -= g.OW; if (++boh[i] == g.OH) { boh[i] = 0; ++bn_[i]; } }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    __bf16* a = As + buf * WBK * PA;
+    __bf16* b = Bs + buf * WBK * PB;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<bf16x8*>(a + ((tid + 256 * i) / AC8) * PA + ac8 * 8) = a_ok[i] ? a_st[i] : zero8;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<bf16x8*>(b + ((tid + 256 * i) / BC8) * PB + bc8 * 8) = b_ok[i] ? b_st[i] : zero8;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int cgrp = 16 * ((lane >> 4) & 1);   // column block of this lane's 16-lane group inside the 32-wide MFMA tile
+  if (t_begin < t_end) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (long t = t_begin; t < t_end; ++t) {
+      const int buf = (int)((t - t_begin) & 1);
+      if (t + 1 < t_end) load_tile();
+      __builtin_amdgcn_sched_barrier(0);
+      const __bf16* a = As + buf * WBK * PA;
+      const __bf16* b = Bs + buf * WBK * PB;
+#pragma unroll
+      for (int s = 0; s < WBK / 16; ++s) {
+        bf16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = tr_frag(a, PA, 16 * s + 8 * lh, wm0 + 32 * i + cgrp, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = tr_frag(b, PB, 16 * s + 8 * lh, wn0 + 32 * j + cgrp, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t_end) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  float* out = part + (long)blockIdx.z * g.Co * g.Ktot;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + li;
+    if (n >= g.Ktot) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < g.Co) out[(long)co * g.Ktot + n] = acc[i][j][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_h_kernel(const float* __restrict__ part, float* __restrict__ dw, long n,
+                                                              int splits, int accumulate) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 3 < n && (n & 3) == 0) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 7 < splits; z += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (long)(z + u) * n + i4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(part + (long)z * n + i4);
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i4);
+    *reinterpret_cast<f32x4*>(dw + i4) = s;
+  } else {
+    for (long i = i4; i < n && i < i4 + 4; ++i) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += part[(long)z * n + i];
+      dw[i] = accumulate ? dw[i] + s : s;
+    }
+  }
+}
+
+static void wgrad_plan_h(long P, int Co, int Ktot, int* splits, int* tiles_per_split) {
+  const long tiles = (long)edrl_cdiv(Co, 128) * edrl_cdiv(Ktot, 128);
+  const long ptiles = (P + WBK - 1) / WBK;
+  long want = (1536 + tiles - 1) / tiles;
+  long max_by_len = ptiles / 16; if (max_by_len < 1) max_by_len = 1;
+  long s = want < max_by_len ? want : max_by_len;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  long tps = (ptiles + s - 1) / s;
+  s = (ptiles + tps - 1) / tps;
+  *splits = (int)(s < 1 ? 1 : s);
+  *tiles_per_split = (int)tps;
+}
+
 // fp32 -> bf16 (round to nearest even), 4 elements per lane
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, long n) {
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
@@ -348,6 +545,44 @@ int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N,
                               : launch_gather_bf16<128, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st);
       if (rc) return rc;
     }
+  return 0;
+}
+
+size_t edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW) {
+  int splits, tps;
+  wgrad_plan_h((long)N * Ho * Wo, Co, KH * KW * Ci, &splits, &tps);
+  return (size_t)splits * Co * KH * KW * Ci * sizeof(float);
+}
+// dw (fp32 [Co,KH,KW,Ci]) [+]= sum_pix dy (bf16) (x) x (bf16).  Co % 8 == 0 and Ci % 8 == 0.
+int edrl_conv2d_nhwc_wgrad_bf16(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_bytes, int N,
+                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                int accumulate, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || (Co % 8) ||
+      (Ci % 8))
+    return EDRL_EINVAL;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return EDRL_EINVAL;
+  WgradGeomH g;
+  g.P = (long)N * Ho * Wo;
+  g.OH = Ho; g.OW = Wo; g.Co = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  int splits;
+  wgrad_plan_h(g.P, Co, g.Ktot, &splits, &g.tiles_per_split);
+  const size_t need = (size_t)splits * Co * g.Ktot * sizeof(float);
+  if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
+  constexpr int BM = 128, BN = 128;
+  const size_t lds = (size_t)2 * WBK * ((BM + 32) + (BN + 32)) * sizeof(__bf16);
+  auto kern = conv_wgrad_bf16_kernel<BM, BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(edrl_cdiv(g.Ktot, BN), edrl_cdiv(Co, BM), splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const __bf16*)dy, (const __bf16*)x, workspace, g);
+  EDRL_LAUNCH_CHECK();
+  const long n = (long)Co * g.Ktot;
+  hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n, splits, accumulate);
+  EDRL_LAUNCH_CHECK();
   return 0;
 }
 

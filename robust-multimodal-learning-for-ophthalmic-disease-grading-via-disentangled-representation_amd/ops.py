@@ -863,3 +863,18 @@ def conv2d_dgrad_bf16(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=Fal
     _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bf16", P(dy), P(wt),
                   P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0)
     return out
+
+
+def conv2d_wgrad_bf16(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False):
+    """dy bf16 [N,Ho,Wo,Co], x bf16 [N,Hi,Wi,Ci] -> dw fp32 [Co,KH,KW,Ci]."""
+    N, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    KH, KW = w_shape[1], w_shape[2]
+    if out is None:
+        out = torch.empty(w_shape, device=dy.device, dtype=torch.float32)
+        accumulate = False
+    nbytes = L.query("edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
+    ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+    _launch_timed("conv_wgrad_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_bf16", P(dy), P(x),
+                  P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 1 if accumulate else 0)
+    return out

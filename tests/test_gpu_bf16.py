@@ -50,6 +50,11 @@ def test_conv_bf16_fwd_dgrad(edrl, dev, case):
         check(f"bf16 conv_dgrad{case}", nchw(dxh.float().cpu()), xd.grad, BF16_TOL)
         dx2 = ops.conv2d_dgrad_bf16(dyh, wt, (N, H, W, Ci), s, p, out=dxh.clone(), accumulate=True)
         check(f"bf16 conv_dgrad_accum{case}", nchw(dx2.float().cpu()), 2 * xd.grad, 2 * BF16_TOL)
+    if Co % 8 == 0:
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+        dwh = ops.conv2d_wgrad_bf16(dyh, x.to(dev), (Co, k, k, Ci), s, p)      # fp32 result: only fp32 accumulation error
+        check(f"bf16 conv_wgrad{case}", dwh.cpu().permute(0, 3, 1, 2), wd.grad, 2e-5)
+        assert torch.equal(dwh, ops.conv2d_wgrad_bf16(dyh, x.to(dev), (Co, k, k, Ci), s, p)), "deterministic split-K"
 
 
 def test_conv_bf16_exact_on_small_integers(edrl, dev):
