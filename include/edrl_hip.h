@@ -121,6 +121,18 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* re
                     int accumulate, float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
                     size_t workspace_bytes, hipStream_t stream);
 
+/* Mixed-precision BatchNorm apply / backward and max-pool of the bf16 (C2) trunk: raw_bf16 / act_bf16 give the storage type
+ * (0 fp32, 1 bf16) of the raw conv output (+ its gradient) and of the activated tensors (+ their gradients); statistics,
+ * affine and reductions stay fp32/fp64.  Dense rows. */
+int edrl_bn_apply_mx(const void* x, int raw_bf16, const float* mean, const float* scale, const float* shift,
+                     const void* residual, void* out, int act_bf16, unsigned char* relu_mask, long M, int C, int relu,
+                     hipStream_t stream);
+int edrl_bn_bwd_mx(const void* dout, int act_bf16, const unsigned char* relu_mask, const void* x, int raw_bf16,
+                   const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
+                   void* dres, long M, int C, float* workspace, size_t workspace_bytes, hipStream_t stream);
+int edrl_maxpool3x3s2_fwd_bf16(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t stream);
+int edrl_maxpool3x3s2_bwd_bf16(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
+                               hipStream_t stream);
 /* 3x3 / stride 2 / pad 1 max pooling on NHWC (encoder stem); idx = window tap of the first max. */
 int edrl_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C,
                               hipStream_t stream);

@@ -43,6 +43,55 @@ def trunk_forward(x, sd, kind, blocks, train=True):
     return x
 
 
+def _q16(t):
+    """Round to bf16 storage (straight-through for autograd): the value the product keeps in HBM."""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
+def conv_bn_bf16_op(x, w, gamma, beta, stride, pad, relu, residual=None):
+    """One conv -> BatchNorm(train) -> (+residual) -> (ReLU) building block of the bf16 trunk, NCHW, working precision
+    of the inputs (fp64 in the tests), with the product's storage roundings (encoders._conv_bn_fwd_bf16): bf16 weights,
+    batch statistics from the UNROUNDED accumulators, conv output rounded to bf16 before normalisation, bf16 result.
+    w is [Co,KH,KW,Ci].  -> (raw_q, out_q, mean, var)."""
+    acc = F.conv2d(x, _q16(w).permute(0, 3, 1, 2)[:, :x.shape[1]], stride=stride, padding=pad)
+    mean = acc.mean(dim=(0, 2, 3), keepdim=True)
+    var = acc.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    raw = _q16(acc)
+    y = (raw - mean) * torch.rsqrt(var + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = F.relu(y)
+    return raw, _q16(y), mean.flatten(), var.flatten()
+
+
+def trunk_forward_bf16(x, sd, kind, blocks):
+    """Storage-aware restatement of the product's bf16 trunk (encoders._TrunkBf16Fn, SURVEY.md §8a rows E1/E2 at
+    C2/C4): same topology as trunk_forward, with a bf16 rounding at exactly the tensors the product stores in bf16
+    (conv_bn_bf16_op).  The stem conv and all BatchNorm arithmetic stay in the working precision.  Training-mode batch
+    statistics only (running statistics are not touched).  Autograd sees straight-through roundings."""
+    def cb(x, cname, bname, stride, pad, relu, residual=None):
+        return conv_bn_bf16_op(x, sd[cname + ".weight"], sd[bname + ".weight"], sd[bname + ".bias"], stride, pad, relu,
+                               residual)[1]
+
+    a = _conv(x, sd, "conv1", 2, 3)
+    mean = a.mean(dim=(0, 2, 3), keepdim=True)
+    var = a.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    a = (a - mean) * torch.rsqrt(var + 1e-5) * sd["bn1.weight"].view(1, -1, 1, 1) + sd["bn1.bias"].view(1, -1, 1, 1)
+    x = F.max_pool2d(_q16(F.relu(a)), 3, 2, 1)
+    for blk in blocks:
+        pre, s = blk["name"], blk["stride"]
+        idn = cb(x, pre + ".downsample.0", pre + ".downsample.1", s, 0, False) if blk["downsample"] else x
+        if kind == "bottleneck":
+            o = cb(x, pre + ".conv1", pre + ".bn1", 1, 0, True)
+            o = cb(o, pre + ".conv2", pre + ".bn2", s, 1, True)
+            x = cb(o, pre + ".conv3", pre + ".bn3", 1, 0, True, idn)
+        else:
+            o = cb(x, pre + ".conv1", pre + ".bn1", s, 1, True)
+            x = cb(o, pre + ".conv2", pre + ".bn2", 1, 1, True, idn)
+    return x
+
+
 def fundus_encoder_forward(x, sd, kind, blocks, proj_w, proj_b, train=True):
     """[B,3,H,W] -> (tokens [B,N2,D], pooled)."""
     f = trunk_forward(x, sd, kind, blocks, train)

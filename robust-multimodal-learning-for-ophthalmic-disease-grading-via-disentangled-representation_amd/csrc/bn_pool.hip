@@ -12,13 +12,34 @@
 
 #define BN_ROWS_PER_CHUNK 1024
 
+// Typed 4-channel accessors: the same kernels serve fp32 tensors and the bf16 activations / gradients of the C2 path
+// (bf16 storage, fp32 statistics and arithmetic).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (float)v[e];
+  return o;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
 // MODE 0: shifted moments (sum (x-K), sum (x-K)^2, K) with K = the chunk's first row: one pass, and no
 //         catastrophic cancellation when var << mean^2 (e.g. BatchNorm1d over 2 rows).
 // MODE 1: (sum g, sum g*xhat) with g = dout * (out > 0 if out given).
 // Partial layout: part[chunk][3][C].
-template <int MODE>
-__global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                      const float* __restrict__ out,
+template <int MODE, typename TR, typename TA>
+__global__ __launch_bounds__(256) void colstat_kernel(const TR* __restrict__ x, const TA* __restrict__ dout,
+                                                      const TA* __restrict__ out,
                                                       const unsigned char* __restrict__ rmask,
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, long M, int C, long ld,
@@ -40,7 +61,7 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
       mu = *reinterpret_cast<const f32x4*>(mean + c);
       rs = *reinterpret_cast<const f32x4*>(rstd + c);
     } else {
-      mu = *reinterpret_cast<const f32x4*>(x + row0 * ld + c);  // shift K
+      mu = ld4<TR>(x + row0 * ld + c);  // shift K
     }
     // 4 rows per iteration: 4 (MODE 0) or 12 (MODE 1) independent 16-B loads in flight per lane
     constexpr int U = 4;
@@ -49,16 +70,16 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
       for (; r + (long)(U - 1) * RL < row1; r += (long)U * RL) {
         f32x4 xv[U], gv[U], ov[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + (r + (long)u * RL) * ld + c);
+        for (int u = 0; u < U; ++u) xv[u] = ld4<TR>(x + (r + (long)u * RL) * ld + c);
         if (MODE == 1) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) gv[u] = *reinterpret_cast<const f32x4*>(dout + (r + (long)u * RL) * ld + c);
+          for (int u = 0; u < U; ++u) gv[u] = ld4<TA>(dout + (r + (long)u * RL) * ld + c);
           if (rmask) {
 #pragma unroll
             for (int u = 0; u < U; ++u) ov[u][0] = (float)rmask[(r + (long)u * RL) * C4 + (c >> 2)];
           } else if (out) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) ov[u] = *reinterpret_cast<const f32x4*>(out + (r + (long)u * RL) * ld + c);
+            for (int u = 0; u < U; ++u) ov[u] = ld4<TA>(out + (r + (long)u * RL) * ld + c);
           }
         }
 #pragma unroll
@@ -83,19 +104,19 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
         }
       }
       for (; r < row1; r += RL) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+        const f32x4 xv = ld4<TR>(x + r * ld + c);
         if (MODE == 0) {
           const f32x4 d = xv - mu;
           s0 += d;
           s1 += d * d;
         } else {
-          f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
+          f32x4 g = ld4<TA>(dout + r * ld + c);
           if (rmask) {
             const int mb = rmask[r * C4 + (c >> 2)];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = (mb >> e) & 1 ? g[e] : 0.f;
           } else if (out) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
+            const f32x4 o = ld4<TA>(out + r * ld + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
           }
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       p[c + e] = a[e]; p[C + c + e] = a[4 + e];
-      if (MODE == 0) p[2 * C + c + e] = x[row0 * ld + c + e];
+      if (MODE == 0) p[2 * C + c + e] = (float)x[row0 * ld + c + e];
     }
   }
 }
@@ -286,23 +307,24 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // out = act((x-mean)*scale + shift + residual)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename TR, typename TA>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TR* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
-                                                       const float* __restrict__ residual,
-                                                       float* __restrict__ out, unsigned char* __restrict__ mask_out,
+                                                       const TA* __restrict__ residual,
+                                                       TA* __restrict__ out, unsigned char* __restrict__ mask_out,
                                                        long M, int C, long ld, int relu) {
   const int C4 = C >> 2;
   const long total = M * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / C4;
     const int c = (int)(i - r * C4) * 4;
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    const f32x4 xv = ld4<TR>(x + r * ld + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c);
     f32x4 v = (xv - mu) * sc + sf;
-    if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * ld + c);
+    if (residual) v += ld4<TA>(residual + r * ld + c);
     if (relu) {
       if (mask_out) {   // 4 ReLU sign bits per float4: the backward reads this byte instead of the 16-B activation
         int mb = 0;
@@ -313,33 +335,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    *reinterpret_cast<f32x4*>(out + r * ld + c) = v;
+    st4<TA>(out + r * ld + c, v);
   }
 }
 
 // g = dout * (out>0);  dx = gamma*rstd*(g - c1 - xhat*c2);  dres (+)= g
+template <typename TR, typename TA>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ rmask,
-    const float* __restrict__ x,
+    const TA* __restrict__ dout, const TA* __restrict__ out, const unsigned char* __restrict__ rmask,
+    const TR* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-    const float* __restrict__ coef, float* __restrict__ dx, float* __restrict__ dres, int dres_accum, long M,
+    const float* __restrict__ coef, TR* __restrict__ dx, TA* __restrict__ dres, int dres_accum, long M,
     int C, long ld) {
   const int C4 = C >> 2;
   const long total = M * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / C4;
     const int c = (int)(i - r * C4) * 4;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * ld + c);
+    f32x4 g = ld4<TA>(dout + r * ld + c);
     if (rmask) {
       const int mb = rmask[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = (mb >> e) & 1 ? g[e] : 0.f;
     } else if (out) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * ld + c);
+      const f32x4 o = ld4<TA>(out + r * ld + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
     }
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    const f32x4 xv = ld4<TR>(x + r * ld + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
     const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + c);
@@ -350,10 +373,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4 d = gm * rs * (g - c1 - xh * c2);
     if (dres) {
       f32x4 v = g;
-      if (dres_accum) v += *reinterpret_cast<const f32x4*>(dres + r * ld + c);
-      *reinterpret_cast<f32x4*>(dres + r * ld + c) = v;
+      if (dres_accum) v += ld4<TA>(dres + r * ld + c);
+      st4<TA>(dres + r * ld + c, v);
     }
-    *reinterpret_cast<f32x4*>(dx + r * ld + c) = d;
+    st4<TR>(dx + r * ld + c, d);
   }
 }
 
@@ -423,7 +446,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
 }
 
 // float4 / 4-byte-index variants (C % 4 == 0): 16 B per lane instead of 4
-__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_v4_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                   unsigned char* __restrict__ idx, int N, int H, int W,
                                                                   int C, int Ho, int Wo) {
   const int C4 = C >> 2;
@@ -445,20 +469,21 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_v4_kernel(const float* _
       for (int kw = 0; kw < 3; ++kw) {
         const int w = wo * 2 - 1 + kw;
         if (w < 0 || w >= W) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + h) * W + w) * C + c);
+        const f32x4 v = ld4<T>(x + (((long)n * H + h) * W + w) * C + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (!any || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
         any = true;
       }
     }
-    *reinterpret_cast<f32x4*>(y + i * 4) = best;
+    st4<T>(y + i * 4, best);
     *reinterpret_cast<unsigned int*>(idx + i * 4) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
   }
 }
-__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v4_kernel(const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v4_kernel(const T* __restrict__ dy,
                                                                   const unsigned char* __restrict__ idx,
-                                                                  float* __restrict__ dx, int N, int H, int W, int C,
+                                                                  T* __restrict__ dx, int N, int H, int W, int C,
                                                                   int Ho, int Wo) {
   const int C4 = C >> 2;
   const long total = (long)N * H * W * C4;
@@ -483,14 +508,14 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v4_kernel(const float* _
         if (wo >= Wo) continue;
         const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
         const unsigned m = *reinterpret_cast<const unsigned int*>(idx + o);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 g = ld4<T>(dy + o);
         const unsigned tap = (unsigned)(kh * 3 + kw);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (((m >> (8 * e)) & 0xff) == tap) s[e] += g[e];
       }
     }
-    *reinterpret_cast<f32x4*>(dx + i * 4) = s;
+    st4<T>(dx + i * 4, s);
   }
 }
 
@@ -554,8 +579,9 @@ int edrl_bn_train_stats_f32(const float* x, long M, int C, long ld, const float*
   if (M <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C) return EDRL_EINVAL;
   if (workspace_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
   const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
-  hipLaunchKernelGGL(colstat_kernel<0>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, M, C, ld, workspace);
+  hipLaunchKernelGGL((colstat_kernel<0, float, float>), dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x,
+                     (const float*)nullptr, (const float*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, M, C, ld, workspace);
   EDRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M,
                      BN_ROWS_PER_CHUNK, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale,
@@ -599,7 +625,7 @@ int edrl_bn_apply_f32(const float* x, const float* mean, const float* scale, con
                       hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3) || (ld & 3)) return EDRL_EINVAL;
   if (relu_mask && ld != C) return EDRL_EINVAL;   // the byte mask is dense [M][C/4]
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, mean, scale, shift, residual,
+  hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, mean, scale, shift, residual,
                      out, relu_mask, M, C, ld, relu);
   EDRL_LAUNCH_CHECK();
   return 0;
@@ -617,13 +643,13 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* re
   if (workspace_bytes < stats + (size_t)2 * C * sizeof(float)) return EDRL_ENOSPC;
   float* coef = workspace + stats / sizeof(float);
   const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
-  hipLaunchKernelGGL(colstat_kernel<1>, dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout, out, relu_mask,
+  hipLaunchKernelGGL((colstat_kernel<1, float, float>), dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout, out, relu_mask,
                      save_mean, save_rstd, M, C, ld, workspace);
   EDRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M,
                      dgamma, dbeta, accumulate, coef);
   EDRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, out, relu_mask, x,
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<float, float>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, out, relu_mask, x,
                      save_mean, save_rstd, gamma, coef, dx, dres, dres_accum, M, C, ld);
   EDRL_LAUNCH_CHECK();
   return 0;
@@ -634,7 +660,7 @@ int edrl_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int 
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   if ((C & 3) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)idx) & 15) == 0)
-    hipLaunchKernelGGL(maxpool3x3s2_fwd_v4_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, y, idx,
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_v4_kernel<float>, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, y, idx,
                        N, H, W, C, Ho, Wo);
   else
     hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, idx, N,
@@ -647,7 +673,7 @@ int edrl_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* 
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   if ((C & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)idx) & 15) == 0)
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_v4_kernel, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, st, dy, idx, dx,
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_v4_kernel<float>, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, st, dy, idx, dx,
                        N, H, W, C, Ho, Wo);
   else
     hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, st, dy, idx, dx, N,
@@ -677,6 +703,81 @@ int edrl_bcast_axis1_f32(const float* in, float* out, long A, int L, int D, floa
   if (A <= 0 || L <= 0 || D <= 0) return EDRL_EINVAL;
   hipLaunchKernelGGL(bcast_axis1_kernel, dim3(ew_grid(A * L * D)), dim3(256), 0, st, in, out, A, L, D, scale,
                      accumulate);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- mixed-precision variants (bf16 activations / gradients, fp32 arithmetic): raw_bf16 / act_bf16 select the types of
+// the raw conv output (and its gradient) and of the activated tensors (and their gradients).  Dense rows (ld == C).
+int edrl_bn_apply_mx(const void* x, int raw_bf16, const float* mean, const float* scale, const float* shift,
+                     const void* residual, void* out, int act_bf16, unsigned char* relu_mask, long M, int C, int relu,
+                     hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
+  const dim3 grid(ew_grid(M * (C / 4)));
+  if (raw_bf16 && act_bf16)
+    hipLaunchKernelGGL((bn_apply_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)x, mean, scale, shift,
+                       (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, (long)C, relu);
+  else if (!raw_bf16 && act_bf16)
+    hipLaunchKernelGGL((bn_apply_kernel<float, __bf16>), grid, dim3(256), 0, st, (const float*)x, mean, scale, shift,
+                       (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, (long)C, relu);
+  else if (!raw_bf16 && !act_bf16)
+    hipLaunchKernelGGL((bn_apply_kernel<float, float>), grid, dim3(256), 0, st, (const float*)x, mean, scale, shift,
+                       (const float*)residual, (float*)out, relu_mask, M, C, (long)C, relu);
+  else
+    return EDRL_EINVAL;
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"
+
+template <typename TR, typename TA>
+static int bn_bwd_mx_impl(const TA* dout, const unsigned char* relu_mask, const TR* x, const float* save_mean,
+                          const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, TR* dx, TA* dres, long M,
+                          int C, float* workspace, hipStream_t st) {
+  const size_t stats = edrl_bn_workspace_bytes(M, C);
+  float* coef = workspace + stats / sizeof(float);
+  const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL((colstat_kernel<1, TR, TA>), dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout,
+                     (const TA*)nullptr, relu_mask, save_mean, save_rstd, M, C, (long)C, workspace);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M, dgamma,
+                     dbeta, 0, coef);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<TR, TA>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, (const TA*)nullptr,
+                     relu_mask, x, save_mean, save_rstd, gamma, coef, dx, dres, 0, M, C, (long)C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" {
+
+int edrl_bn_bwd_mx(const void* dout, int act_bf16, const unsigned char* relu_mask, const void* x, int raw_bf16,
+                   const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
+                   void* dres, long M, int C, float* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
+  if (workspace_bytes < edrl_bn_workspace_bytes(M, C) + (size_t)2 * C * sizeof(float)) return EDRL_ENOSPC;
+  if (raw_bf16 && act_bf16)
+    return bn_bwd_mx_impl<__bf16, __bf16>((const __bf16*)dout, relu_mask, (const __bf16*)x, save_mean, save_rstd, gamma,
+                                          dgamma, dbeta, (__bf16*)dx, (__bf16*)dres, M, C, workspace, st);
+  if (!raw_bf16 && act_bf16)
+    return bn_bwd_mx_impl<float, __bf16>((const __bf16*)dout, relu_mask, (const float*)x, save_mean, save_rstd, gamma, dgamma,
+                                         dbeta, (float*)dx, (__bf16*)dres, M, C, workspace, st);
+  return EDRL_EINVAL;
+}
+int edrl_maxpool3x3s2_fwd_bf16(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_v4_kernel<__bf16>, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0, st,
+                     (const __bf16*)x, (__bf16*)y, idx, N, H, W, C, Ho, Wo);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_maxpool3x3s2_bwd_bf16(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
+                               hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_v4_kernel<__bf16>, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, st,
+                     (const __bf16*)dy, idx, (__bf16*)dx, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

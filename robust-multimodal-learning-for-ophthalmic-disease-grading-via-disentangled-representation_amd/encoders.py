@@ -227,11 +227,166 @@ class _TrunkFn(torch.autograd.Function):
         return (None, dx) + tuple(grads.get(n) for n in T.param_names)
 
 
+# ------------------------------------------------------------------------------------------------ bf16 trunk (C2/C4)
+def _conv_bn_fwd_bf16(inp, w, bn, stride, pad, relu, residual=None):
+    """bf16 conv (fp32 accumulate, BN statistics from the accumulators) -> BN -> (+residual) -> (ReLU), all tensors bf16.
+    -> (raw bf16, out bf16, mean, rstd, mask)."""
+    raw, part, chunks = ops.conv2d_fwd_bf16(inp, ops.to_bf16(w), stride, pad, stats=True)
+    C = raw.shape[-1]
+    M = raw.numel() // C
+    dev = raw.device
+    mean = torch.empty(C, device=dev, dtype=torch.float32)
+    rstd = torch.empty_like(mean); scale = torch.empty_like(mean); shift = torch.empty_like(mean)
+    gbytes = L.query("edrl_bn_finalize_group_ws_bytes", chunks, C)
+    gws = torch.empty(max(gbytes // 8, 1), device=dev, dtype=torch.float64)
+    L.call("edrl_bn_finalize_partials_f32", P(part), chunks, 128, M, C, P(bn["weight"]), P(bn["bias"]),
+           P(bn["running_mean"]), P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(mean), P(rstd),
+           P(scale), P(shift), P(gws), gbytes)
+    out = torch.empty_like(raw)
+    mask = torch.empty((M, C // 4), device=dev, dtype=torch.uint8) if relu else None
+    L.call("edrl_bn_apply_mx", P(raw), 1, P(mean), P(scale), P(shift), P(residual), P(out), 1, P(mask), M, C,
+           1 if relu else 0)
+    return raw, out, mean, rstd, mask
+
+
+def _bn_bwd_mx(dout, mask, raw, mean, rstd, gamma, want_dres):
+    """BN(+ReLU) backward with bf16 gradients; d_raw takes the storage type of `raw` (bf16, or fp32 for the stem)."""
+    C = raw.shape[-1]
+    M = raw.numel() // C
+    dev = raw.device
+    d_raw = torch.empty_like(raw)
+    dgamma = torch.empty(C, device=dev, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    dres = torch.empty(raw.shape, device=dev, dtype=torch.bfloat16) if want_dres else None
+    ws, nbytes = _bn_ws(M, C, dev, extra=2 * C * 4)
+    L.call("edrl_bn_bwd_mx", P(dout), 1, P(mask), P(raw), 1 if raw.dtype == torch.bfloat16 else 0, P(mean), P(rstd),
+           P(gamma), P(dgamma), P(dbeta), P(d_raw), P(dres), M, C, P(ws), nbytes)
+    return d_raw, dgamma, dbeta, dres
+
+
+class _TrunkBf16Fn(torch.autograd.Function):
+    """The same trunk with bf16 activations / gradients and bf16 MFMA convolutions (fp32 accumulate; BatchNorm statistics,
+    affine and all reductions in fp32; weights and their gradients fp32).  The stem conv (Cin = 1 or 4) stays fp32.
+    x NHWC fp32 -> feature map NHWC fp32 (cast once at the boundary to the fp32 head)."""
+
+    @staticmethod
+    def forward(ctx, trunk, x, *params):
+        T = trunk
+        p = dict(zip(T.param_names, params))
+        bnd = T.bn_dict
+        saved = {}
+        x = ops._chk(x, "encoder input")
+
+        def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
+            return _conv_bn_fwd_bf16(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
+
+        # stem: fp32 conv + fp32 statistics, bf16 activation out
+        raw = ops.conv2d_fwd(x, p["conv1.weight"], stride=2, pad=3)
+        bn = bnd("bn1", p)
+        C = raw.shape[-1]
+        M = raw.numel() // C
+        dev = raw.device
+        m0 = torch.empty(C, device=dev, dtype=torch.float32)
+        r0 = torch.empty_like(m0); scale = torch.empty_like(m0); shift = torch.empty_like(m0)
+        ws, nbytes = _bn_ws(M, C, dev)
+        L.call("edrl_bn_train_stats_f32", P(raw), M, C, C, P(bn["weight"]), P(bn["bias"]), P(bn["running_mean"]),
+               P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(m0), P(r0), P(scale), P(shift), P(ws), nbytes)
+        a0 = torch.empty(raw.shape, device=dev, dtype=torch.bfloat16)
+        k0 = torch.empty((M, C // 4), device=dev, dtype=torch.uint8)
+        L.call("edrl_bn_apply_mx", P(raw), 0, P(m0), P(scale), P(shift), None, P(a0), 1, P(k0), M, C, 1)
+        N, H, W, _ = a0.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        p0 = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.bfloat16)
+        idx = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.uint8)
+        L.call("edrl_maxpool3x3s2_fwd_bf16", P(a0), P(p0), P(idx), N, H, W, C)
+        saved["stem"] = (x, raw, a0.shape, m0, r0, k0, idx)
+        cur = p0
+        for blk in T.blocks:
+            pre, s = blk["name"], blk["stride"]
+            rec = {"x": cur}
+            if blk["downsample"]:
+                cd, idn, md, rd, _ = cb(pre + ".downsample.0", pre + ".downsample.1", cur, s, 0, False)
+                rec.update(cd=cd, sd=(md, rd))
+            else:
+                idn = cur
+            if T.kind == "bottleneck":
+                c1, a1, m1, r1, k1 = cb(pre + ".conv1", pre + ".bn1", cur, 1, 0, True)
+                c2, a2, m2, r2, k2 = cb(pre + ".conv2", pre + ".bn2", a1, s, 1, True)
+                c3, out, ml, rl, kl = cb(pre + ".conv3", pre + ".bn3", a2, 1, 0, True, residual=idn)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2, a2=a2, s2=(m2, r2), k2=k2, c3=c3)
+            else:
+                c1, a1, m1, r1, k1 = cb(pre + ".conv1", pre + ".bn1", cur, s, 1, True)
+                c2, out, ml, rl, kl = cb(pre + ".conv2", pre + ".bn2", a1, 1, 1, True, residual=idn)
+                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2)
+            rec.update(sl=(ml, rl), kl=kl)
+            saved[pre] = rec
+            cur = out
+        ctx.trunk, ctx.saved, ctx.params = T, saved, p
+        T.bump_batches_tracked()
+        return ops.to_f32(cur)
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, saved, p = ctx.trunk, ctx.saved, ctx.params
+        ctx.saved = None
+        grads = {}
+        dcur = ops.to_bf16(dout.contiguous())
+
+        def conv_bwd(name, dy, inp, stride, pad, dx_out=None, accumulate=False):
+            w = p[name + ".weight"]
+            grads[name + ".weight"] = ops.conv2d_wgrad_bf16(dy, inp, tuple(w.shape), stride, pad)
+            return ops.conv2d_dgrad_bf16(dy, ops.permute_weight_bf16(w), tuple(inp.shape), stride, pad, out=dx_out,
+                                         accumulate=accumulate)
+
+        def bn_bwd(name, dy, mask, raw, st, want_dres=False):
+            d_raw, dg, db, dres = _bn_bwd_mx(dy, mask, raw, st[0], st[1], p[name + ".weight"], want_dres)
+            grads[name + ".weight"] = dg
+            grads[name + ".bias"] = db
+            return d_raw, dres
+
+        for blk in reversed(T.blocks):
+            pre, s = blk["name"], blk["stride"]
+            rec = saved.pop(pre)
+            xin = rec["x"]
+            last = "c3" if T.kind == "bottleneck" else "c2"
+            last_bn = pre + (".bn3" if T.kind == "bottleneck" else ".bn2")
+            d3, g = bn_bwd(last_bn, dcur, rec["kl"], rec[last], rec["sl"], want_dres=True)
+            if T.kind == "bottleneck":
+                da2 = conv_bwd(pre + ".conv3", d3, rec["a2"], 1, 0)
+                d2, _ = bn_bwd(pre + ".bn2", da2, rec["k2"], rec["c2"], rec["s2"])
+                da1 = conv_bwd(pre + ".conv2", d2, rec["a1"], s, 1)
+                d1, _ = bn_bwd(pre + ".bn1", da1, rec["k1"], rec["c1"], rec["s1"])
+                c1_stride, c1_pad = 1, 0
+            else:
+                da1 = conv_bwd(pre + ".conv2", d3, rec["a1"], 1, 1)
+                d1, _ = bn_bwd(pre + ".bn1", da1, rec["k1"], rec["c1"], rec["s1"])
+                c1_stride, c1_pad = s, 1
+            if blk["downsample"]:
+                dx = conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad)
+                dd, _ = bn_bwd(pre + ".downsample.1", g, None, rec["cd"], rec["sd"])
+                conv_bwd(pre + ".downsample.0", dd, xin, s, 0, dx_out=dx, accumulate=True)
+            else:
+                dx = g
+                conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad, dx_out=dx, accumulate=True)
+            dcur = dx
+            del rec, g
+        x, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
+        N, H, W, C = a0_shape
+        da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.bfloat16)
+        L.call("edrl_maxpool3x3s2_bwd_bf16", P(dcur), P(idx), P(da0), N, H, W, C)
+        draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))            # raw is fp32 -> fp32 gradient for the fp32 stem wgrad
+        w1 = p["conv1.weight"]
+        grads["conv1.weight"] = ops.conv2d_wgrad(draw, x, tuple(w1.shape), 2, 3)
+        return (None, None) + tuple(grads.get(n) for n in T.param_names)
+
+
 class ResNetTrunk(nn.Module):
     """ResNet-18/34/50 trunk (no fc), NHWC fp32, HIP kernels only."""
 
-    def __init__(self, depth=50, in_ch=3):
+    def __init__(self, depth=50, in_ch=3, dtype="fp32"):
         super().__init__()
+        assert dtype in ("fp32", "bf16")
+        self.compute_dtype = dtype
         kind, layers, expansion = _CFG[depth]
         self.kind, self.depth, self.in_ch = kind, depth, in_ch
         self.in_ch_padded = in_ch if in_ch == 1 else (in_ch + 3) // 4 * 4
@@ -309,6 +464,8 @@ class ResNetTrunk(nn.Module):
         if not self.training:
             return self.forward_eval(x_nhwc)
         params = [self.get(n) for n in self.param_names]
+        if self.compute_dtype == "bf16":
+            return _TrunkBf16Fn.apply(self, x_nhwc, *params)
         return _TrunkFn.apply(self, x_nhwc, *params)
 
     @torch.no_grad()
@@ -347,9 +504,9 @@ class FundusEncoder(nn.Module):
     """2D fundus encoder slot: [B,3,H,W] (NCHW, as the loader emits, data_harvard.py:830-841)
     -> (tokens [B, (H/32)*(W/32), token_dim], pooled [B, token_dim])."""
 
-    def __init__(self, depth=50, token_dim=1024):
+    def __init__(self, depth=50, token_dim=1024, dtype="fp32"):
         super().__init__()
-        self.trunk = ResNetTrunk(depth, in_ch=3)
+        self.trunk = ResNetTrunk(depth, in_ch=3, dtype=dtype)
         c = self.trunk.out_channels
         self.token_proj = nn.Linear(c, token_dim)
 
@@ -369,9 +526,9 @@ class OCTSliceEncoder(nn.Module):
     """OCT slice-stack encoder slot: [B,1,S,H,W] -> (tokens [B, S, token_dim], pooled [B, token_dim]).
     The S slices run through the 2D trunk as a batch of B*S single-channel images."""
 
-    def __init__(self, depth=50, token_dim=768):
+    def __init__(self, depth=50, token_dim=768, dtype="fp32"):
         super().__init__()
-        self.trunk = ResNetTrunk(depth, in_ch=1)
+        self.trunk = ResNetTrunk(depth, in_ch=1, dtype=dtype)
         c = self.trunk.out_channels
         self.token_proj = nn.Linear(c, token_dim)
 

@@ -258,7 +258,8 @@ class DILR(nn.Module):
 
 class MedFusion(nn.Module):
     """MedFusion(classes, modalties, classifiers_dims, args): args.mode, args.batch_size (per-GPU batch) as in
-    the reference; optional args.encoder_depth (18|34|50, default 50), args.rng ("device"|"reference"),
+    the reference; optional args.encoder_depth (18|34|50, default 50), args.encoder_dtype ("fp32"|"bf16"),
+    args.rng ("device"|"reference"),
     args.strict_labels (default True: raise on labels outside {0,1} like the reference's KeyError)."""
 
     def __init__(self, classes, modalties, classifiers_dims, args):
@@ -268,8 +269,9 @@ class MedFusion(nn.Module):
         self.num_classes, self.topk_fundus, self.topk_oct = 2, 1, 1
         self.sample_num, self.seed, self.head = 800, 1, 8
         depth = getattr(args, "encoder_depth", 50)
-        self.transformer_2DNet = FundusEncoder(depth, self.fundus_embedding_dim)
-        self.transformer_3DNet = OCTSliceEncoder(depth, self.oct_embedding_dim)
+        enc_dtype = getattr(args, "encoder_dtype", "fp32")      # "bf16": bf16 MFMA encoders (C2/C4), fp32 head
+        self.transformer_2DNet = FundusEncoder(depth, self.fundus_embedding_dim, enc_dtype)
+        self.transformer_3DNet = OCTSliceEncoder(depth, self.oct_embedding_dim, enc_dtype)
         self.fc_fundus = nn.Sequential(nn.ReLU(), nn.Linear(512, 1024), nn.ReLU())
         self.fc = nn.Sequential(nn.ReLU(), nn.Linear(3072, 64), nn.ReLU(), nn.Linear(64, self.classes))
         self.EPRL_fundus = EPRL(self.fundus_embedding_dim, num_classes=self.num_classes, topk=self.topk_fundus,

@@ -1,0 +1,36 @@
+import sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, ".")
+import edrl_amd as edrl
+from edrl_amd_pkg import encoders as E
+dev = torch.device("cuda:0")
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+N, H = 4, 128
+torch.manual_seed(0)
+q = lambda t: t.to(torch.bfloat16).to(t.dtype)
+orig = E._conv_bn_fwd_bf16
+cnt = [0]
+def patched(inp, w, bn, stride, pad, relu, residual=None):
+    raw, out, mean, rstd, mask = orig(inp, w, bn, stride, pad, relu, residual)
+    cnt[0] += 1
+    if cnt[0] > 12: return raw, out, mean, rstd, mask
+    x = inp.float().cpu().double(); wd = q(w.cpu()).double()
+    acc = F.conv2d(x.permute(0, 3, 1, 2), wd.permute(0, 3, 1, 2), stride=stride, padding=pad)
+    m = acc.mean((0, 2, 3), keepdim=True); v = acc.var((0, 2, 3), unbiased=False, keepdim=True)
+    y = (q(acc) - m) * torch.rsqrt(v + 1e-5) * bn["weight"].cpu().double().view(1, -1, 1, 1) + bn["bias"].cpu().double().view(1, -1, 1, 1)
+    if residual is not None: y = y + residual.float().cpu().double().permute(0, 3, 1, 2)
+    if relu: y = F.relu(y)
+    y = q(y).permute(0, 2, 3, 1)
+    o = out.float().cpu().double()
+    e_raw = float((raw.float().cpu().double() - q(acc).permute(0, 2, 3, 1)).norm() / acc.norm())
+    e_mean = float((mean.cpu().double() - m.flatten()).abs().max() / m.abs().max())
+    e_rstd = float((rstd.cpu().double() * torch.sqrt(v.flatten() + 1e-5) - 1).abs().max())
+    ratio = float((m.flatten().abs() / v.flatten().sqrt()).max())
+    print(f"conv#{cnt[0]} {tuple(inp.shape)}->{raw.shape[-1]} k{w.shape[1]} s{stride}: raw {e_raw:.2e} mean {e_mean:.2e} rstd {e_rstd:.2e} out fro {float((o - y).norm() / y.norm()):.2e} max|mean|/std {ratio:.2f}", flush=True)
+    return raw, out, mean, rstd, mask
+E._conv_bn_fwd_bf16 = patched
+t16 = edrl.ResNetTrunk(depth, 3, dtype="bf16").to(dev).train()
+x = torch.rand(N, 3, H, H)
+xh = torch.zeros(N, H, H, t16.in_ch_padded); xh[..., :3] = x.permute(0, 2, 3, 1)
+with torch.no_grad():
+    t16(xh.to(dev))

@@ -91,3 +91,154 @@ def test_conv_bf16_fused_stats_and_casts(edrl, dev):
     # statistics come from the fp32 accumulators (before the bf16 rounding of y): compare with the exact conv
     check("bf16 fused mean", outs[0].cpu(), yd.mean(0), 1e-4)
     check("bf16 fused rstd", outs[1].cpu(), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-4)
+
+
+@pytest.mark.parametrize("depth,in_ch,N,H", [(18, 1, 8, 96), (50, 3, 4, 128)])
+def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, monkeypatch):
+    """bf16 trunk (bf16 MFMA convs, bf16 activations/gradients, fp32 BN statistics) against the fp64 oracle.
+
+    (1) PER LAYER, tight: every conv->BN->(+res)->(ReLU) call the trunk makes is re-done by the oracle's storage-aware
+        fp64 op (oracle/resnet_oracle.conv_bn_bf16_op) on the product's own bf16 inputs.  What is left is accumulation
+        order plus 1-ulp(bf16) rounding flips of a ~1e-4 fraction of the elements: conv output and block output within
+        3e-4 norm-wise (Frobenius), batch mean within 1e-5 of its max, rstd within 1e-5 relative.
+    (2) END TO END, envelope: a rounding turns a perturbation d into an error ~sqrt(d*ulp), so two bf16-storage
+        pipelines decorrelate with depth up to the bf16-storage drift itself; the product's distance to the UNROUNDED
+        fp64 trunk must stay within 1.25x the distance the storage-aware oracle itself shows (+1e-3).
+    (3) Parameter gradients: finite, and for every tensor whose direction survives bf16 storage at all (the
+        storage-aware oracle's straight-through gradient has cosine > 0.9 to the fp64 trunk's), the product's cosine
+        is no worse than the oracle's minus 0.05."""
+    from oracle import resnet_oracle as RO
+    import edrl_amd_pkg.encoders as E
+    torch.manual_seed(0)
+    trunk = edrl.ResNetTrunk(depth, in_ch, dtype="bf16").to(dev).train()
+    last_bn = ".bn3.weight" if trunk.kind == "bottleneck" else ".bn2.weight"
+    with torch.no_grad():                       # damp the residual branches (as zero-init-residual training recipes do):
+        for n, p in trunk.named_parameters():   # a gamma=1 random-init stack is chaotic at these tiny batch sizes
+            if n.endswith(last_bn):
+                p.fill_(0.25)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(N, in_ch, H, H, generator=g)
+    sd_full = RO.trunk_state(trunk)
+    sd_q = RO.trunk_state(trunk)
+    f_full = RO.trunk_forward(x.double(), sd_full, trunk.kind, trunk.blocks)
+    f_q = RO.trunk_forward_bf16(x.double(), sd_q, trunk.kind, trunk.blocks)
+    gy = torch.randn(f_full.shape, generator=g)
+    f_full.backward(gy.double())
+    f_q.backward(gy.double())
+
+    product_op = E._conv_bn_fwd_bf16
+    worst = dict(raw=0.0, out=0.0, mean=0.0, rstd=0.0, n=0)
+
+    def checked(inp, w, bn, stride, pad, relu, residual=None):
+        res = product_op(inp, w, bn, stride, pad, relu, residual)
+        raw, out, mean, rstd, _ = res
+        nchw = lambda t: t.float().cpu().double().permute(0, 3, 1, 2)
+        r_raw, r_out, r_mean, r_var = RO.conv_bn_bf16_op(
+            nchw(inp), w.detach().cpu().double(), bn["weight"].detach().cpu().double(),
+            bn["bias"].detach().cpu().double(), stride, pad, relu, None if residual is None else nchw(residual))
+        worst["raw"] = max(worst["raw"], float((nchw(raw) - r_raw).norm() / r_raw.norm()))
+        worst["out"] = max(worst["out"], float((nchw(out) - r_out).norm() / r_out.norm().clamp_min(1e-30)))
+        worst["mean"] = max(worst["mean"], float((mean.cpu().double() - r_mean).abs().max() / r_mean.abs().max()))
+        worst["rstd"] = max(worst["rstd"], float((rstd.cpu().double() * torch.sqrt(r_var + 1e-5) - 1).abs().max()))
+        worst["n"] += 1
+        return res
+
+    monkeypatch.setattr(E, "_conv_bn_fwd_bf16", checked)
+    cp = trunk.in_ch_padded
+    xh = torch.zeros(N, H, H, cp)
+    xh[..., :in_ch] = x.permute(0, 2, 3, 1)
+    f = trunk(xh.to(dev))
+    monkeypatch.setattr(E, "_conv_bn_fwd_bf16", product_op)
+    assert f.dtype == torch.float32
+    n_convs = sum(1 for n in trunk.param_names if n.endswith(".weight") and "conv" in n or "downsample.0" in n) - 1
+    print(f"[parity] bf16 trunk{depth}: {worst['n']} conv+BN layers checked per layer: raw {worst['raw']:.2e} "
+          f"out {worst['out']:.2e} (tol 3e-4)  mean {worst['mean']:.2e} rstd {worst['rstd']:.2e} (tol 1e-5)")
+    assert worst["n"] == n_convs
+    assert worst["raw"] < 3e-4 and worst["out"] < 3e-4 and worst["mean"] < 1e-5 and worst["rstd"] < 1e-5
+
+    fh = f.permute(0, 3, 1, 2).cpu().double()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    e_prod, e_env = rel(fh, f_full.detach()), rel(f_q.detach(), f_full.detach())
+    print(f"[parity] bf16 trunk{depth}_fwd: distance to fp64 trunk {e_prod:.3e}; storage-aware oracle's own {e_env:.3e}")
+    assert e_prod < 1.25 * e_env + 1e-3
+
+    f.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+    cosf = lambda a, b: float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+    margin, wn, n_checked = 1.0, "", 0
+    for n, p in trunk.named_parameters():
+        ref = sd_full[n].grad.flatten()
+        got = p.grad.cpu().double().flatten()
+        assert torch.isfinite(got).all(), n
+        if ref.norm() < 1e-6 * max(1.0, float(sd_full[n].detach().norm())):
+            continue
+        if cosf(sd_q[n].grad.flatten(), ref) < 0.9:
+            continue
+        n_checked += 1
+        m = cosf(got, ref) - cosf(sd_q[n].grad.flatten(), ref)
+        if m < margin:
+            margin, wn = m, f"{n}: product {cosf(got, ref):.4f} oracle {cosf(sd_q[n].grad.flatten(), ref):.4f}"
+    print(f"[parity] bf16 trunk{depth} gradients: {n_checked} tensors, worst cosine margin vs storage-aware oracle "
+          f"{margin:+.4f} ({wn})")
+    assert margin > -0.05 and n_checked > len(trunk.param_names) // 2
+
+
+def test_bn_mx_kernels_vs_torch(edrl, dev):
+    """edrl_bn_apply_mx / edrl_bn_bwd_mx (bf16 and fp32 raw storage) against fp64 torch autograd on the same bf16
+    inputs: outputs are bf16, so element-wise tolerance 2^-8 of the tensor max; dgamma/dbeta (fp32 reductions) 1e-4."""
+    from edrl_amd_pkg import _lib as L
+    from edrl_amd_pkg import encoders as E
+    P = L.ptr
+    torch.manual_seed(3)
+    M, C = 4 * 14 * 14, 256
+    for raw_dtype in (torch.bfloat16, torch.float32):
+        raw = (torch.randn(M, C) * 1.5 + 0.3).to(raw_dtype)
+        res = torch.randn(M, C).bfloat16()
+        gamma = torch.rand(C) + 0.5
+        beta = torch.randn(C) * 0.1
+        mean = raw.double().mean(0)
+        var = raw.double().var(0, unbiased=False)
+        rstd = torch.rsqrt(var + 1e-5)
+        scale = (gamma.double() * rstd).float()
+        shift = beta.clone()
+        d = lambda t: None if t is None else t.to(dev)
+        out = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        mask = torch.empty(M, C // 4, device=dev, dtype=torch.uint8)
+        rawd, resd = d(raw), d(res)
+        meand, rstdd, scaled, shiftd = d(mean.float()), d(rstd.float()), d(scale), d(shift)
+        L.call("edrl_bn_apply_mx", P(rawd), int(raw_dtype == torch.bfloat16), P(meand), P(scaled), P(shiftd),
+               P(resd), P(out), 1, P(mask), M, C, 1)
+        rawr = raw.double().requires_grad_(True)
+        resr = res.double().requires_grad_(True)
+        y = torch.relu((rawr - mean) * rstd * gamma.double() + beta.double() + resr)
+        check(f"bn_apply_mx[{raw_dtype}]", out.float().cpu(), y.detach(), 2 ** -8)
+        dy = torch.randn(M, C).bfloat16()
+        gd = gamma.double().requires_grad_(True)
+        bd = beta.double().requires_grad_(True)
+        m2 = rawr.mean(0)
+        v2 = rawr.var(0, unbiased=False)
+        y2 = torch.relu((rawr - m2) * torch.rsqrt(v2 + 1e-5) * gd + bd + resr)
+        y2.backward(dy.double())
+        dyd, gammad = d(dy), d(gamma)
+        d_raw, dg, db, dres = E._bn_bwd_mx(dyd, mask, rawd, meand, rstdd, gammad, True)
+        assert d_raw.dtype == raw_dtype
+        check(f"bn_bwd_mx[{raw_dtype}] d_raw", d_raw.float().cpu(), rawr.grad, 2 ** -8)
+        check(f"bn_bwd_mx[{raw_dtype}] dres", dres.float().cpu(), resr.grad, 2 ** -8)
+        check(f"bn_bwd_mx[{raw_dtype}] dgamma", dg.cpu(), gd.grad, 1e-4)
+        check(f"bn_bwd_mx[{raw_dtype}] dbeta", db.cpu(), bd.grad, 1e-4)
+    # bf16 max-pool: exact on bf16 values
+    x = torch.randn(2, 17, 19, 64).bfloat16()
+    N_, H_, W_, C_ = x.shape
+    Ho, Wo = (H_ - 1) // 2 + 1, (W_ - 1) // 2 + 1
+    xd = x.to(dev)
+    o = torch.empty(N_, Ho, Wo, C_, device=dev, dtype=torch.bfloat16)
+    idx = torch.empty(N_, Ho, Wo, C_, device=dev, dtype=torch.uint8)
+    L.call("edrl_maxpool3x3s2_fwd_bf16", P(xd), P(o), P(idx), N_, H_, W_, C_)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(o.float().cpu().double().permute(0, 3, 1, 2), yr.detach())
+    go = torch.randn(N_, Ho, Wo, C_).bfloat16()
+    yr.backward(go.double().permute(0, 3, 1, 2))
+    dxd = torch.empty_like(xd)
+    god = go.to(dev)
+    L.call("edrl_maxpool3x3s2_bwd_bf16", P(god), P(idx), P(dxd), N_, H_, W_, C_)
+    check("maxpool_bwd_bf16", dxd.float().cpu().permute(0, 3, 1, 2), xr.grad, 2 ** -8)
