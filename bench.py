@@ -21,11 +21,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (per-GPU batch, encoder depth, H=W, slices, description)
-    "C0": (2, 18, 224, 16, "C0: B=2/GPU, ResNet-18 encoders, 224x224 fundus + 16-slice OCT, fp32"),
-    "C1": (32, 50, 224, 32, "C1: B=32/GPU, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32"),
+    # name: (per-GPU batch, encoder depth, H=W, slices, encoder dtype, description)
+    "C0": (2, 18, 224, 16, "fp32", "C0: B=2/GPU, ResNet-18 encoders, 224x224 fundus + 16-slice OCT, fp32"),
+    "C1": (32, 50, 224, 32, "fp32", "C1: B=32/GPU, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32"),
+    # BASELINE.json configs[2]; NOT the default bench line (the metric is quoted on C1/fp32): bf16 MFMA encoders
+    # (bf16 activations/gradients, fp32 accumulate + fp32 BatchNorm statistics + fp32 weights/Adam), fp32 head.
+    "C2": (64, 50, 224, 32, "bf16", "C2: B=64/GPU, ResNet-50 encoders on the bf16 MFMA path, 224x224 fundus + 32-slice OCT"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense, 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 
 
 def main():
@@ -61,11 +65,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    B, depth, HW, S, desc = CONFIGS[a.config]
+    B, depth, HW, S, enc_dtype, desc = CONFIGS[a.config]
     if a.batch:
         B = a.batch
         desc = desc.replace(f"B={CONFIGS[a.config][0]}/GPU", f"B={B}/GPU (override)")
-    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, strict_labels=False)
+    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, strict_labels=False,
+                                 encoder_dtype=enc_dtype)
     torch.manual_seed(0)
     model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
     edrl_amd.broadcast_parameters(model)
@@ -113,7 +118,7 @@ def main():
         res = {
             "metric": "train images/sec (fundus+OCT pair)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": enc_dtype, "data": "synthetic",
             "config": {"workload": desc, "global_batch": B * world, "per_gpu_batch": B, "encoder": f"resnet{depth}",
                        "fundus": [3, HW, HW], "oct": [1, S, HW, HW], "parallelism": f"dp{world}",
                        "optimizer": "Adam(lr=1e-4, weight_decay=1e-6)"},
@@ -122,13 +127,16 @@ def main():
         }
         if timer is not None:
             ks = timer.summary()
-            dom = ks.get("conv_gather")
+            dom = ks.get("conv_gather_bf16" if enc_dtype == "bf16" else "conv_gather")
             if dom:
                 avg_ms = dom["ms"] / dom["launches"]
+                peak = PEAK_BF16_MFMA_TFLOPS if enc_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
                 res["roofline"] = {
-                    "kernel": "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)",
-                    "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": ("conv_gather_bf16_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x16_bf16)"
+                               if enc_dtype == "bf16" else
+                               "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)"),
+                    "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
                     "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                     "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
