@@ -235,7 +235,13 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
 // issued in four pieces, one per 8-deep MFMA chunk, so that its address arithmetic and the loads sit in
 // the shadow of the 64-cycle fp32 MFMAs instead of in front of them.  The (tap, channel) decode of the
 // K index advances incrementally (no integer division in the loop).
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// BUF (FAST only; host-checked footprints < 2 GiB): both operands come through buffer descriptors -- the gathered one
+// through a per-workgroup descriptor based at the first image the tile's rows touch -- so masked rows / taps are an
+// out-of-range 32-bit offset that the range check zero-fills: no 64-bit address arithmetic, no selects on the address
+// or on the data, one add per staged piece and tile.
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n) {
@@ -292,9 +298,49 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   // (every SC/BKT tiles; never for 1x1 convs and Linear layers) and a staging piece costs ~one add + select.
   long rowoff[A_LD];   // element offset of the row's source pixel for the current tap, -1 = masked
   long tapoff = 0;     // (kh*KW + kw)*SC of the current tap
+  // ---- BUF state: byte offsets into the two descriptors; >= 2 GiB = masked (stays masked under the per-tile adds)
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned aoff[A_LD], boff[B_LD], wrow4[B_LD];
+  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  int n_first = 0;
+  int cb = 0;          // uniform part of c (c = cb + k4 while FAST)
+  if constexpr (BUF) {
+    const int ohw = g.OHs * g.OWs;
+    long mlast = m0 + BM; if (mlast > g.M) mlast = g.M;
+    n_first = (int)(m0 / ohw);
+    const int n_last = (int)((mlast - 1) / ohw);
+    const unsigned a_bytes = (unsigned)(((long)(n_last - n_first + 1) * g.SH * g.SW - 1) * g.ld_src * 4 + (long)g.SC * 4);
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
+    rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, (int)((long)g.NC * g.Kfull * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int n = n0 + r0 + RPP * i;
+      wrow4[i] = n < g.NC ? (unsigned)n * (unsigned)g.Kfull * 4u : OOB;
+    }
+  }
   auto retap = [&]() {
     const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
     tapoff = (long)(kh * g.KW + kw) * g.SC;
+    if constexpr (BUF) {
+      const bool kvalid = ta < g.KHs && g.KWs > 0;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int sh, sw;
+        bool ok = kvalid && rn[i] >= 0;
+        if (DGRAD) {
+          const int th = rh[i] - kh, tw = rw[i] - kw;
+          ok = ok && th >= 0 && tw >= 0;
+          sh = th >> g.sshift; sw = tw >> g.sshift;
+        } else { sh = rh[i] + kh; sw = rw[i] + kw; }
+        ok = ok && (unsigned)sh < (unsigned)g.SH && (unsigned)sw < (unsigned)g.SW;
+        const unsigned pix = (unsigned)(((rn[i] - n_first) * g.SH + sh) * g.SW + sw);
+        aoff[i] = ok ? pix * (unsigned)(g.ld_src * 4) + (unsigned)(cb + k4) * 4u : OOB;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        boff[i] = kvalid ? wrow4[i] + (unsigned)((int)tapoff + cb + k4) * 4u : OOB;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       int sh, sw;
@@ -310,6 +356,17 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   };
   if (FAST) retap();
   auto advance = [&]() {
+    if constexpr (BUF) {   // the tap change is decided on the uniform part of the channel offset: a scalar branch
+      cb += BKT;
+      if (cb >= g.SC) { cb -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
+      else {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) aoff[i] += BKT * 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) boff[i] += BKT * 4;
+      }
+      return;
+    }
     c += BKT; kk += BKT;
     if (FAST) {
       if (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
@@ -322,6 +379,11 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   bool a_ok[A_LD], b_ok[B_LD];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_piece = [&](int i) {
+    if constexpr (BUF) {
+      a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)aoff[i], 0, 0));
+      if (i < B_LD) b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)boff[i], 0, 0));
+      return;
+    }
     const bool kvalid = kk < g.Ktot;   // (a class of the strided dgrad may have no taps at all: Ktot == 0)
     if (FAST) {   // raw load now, zero-select at store time (keeps the wait for the data off the MFMA chain's head)
       {
@@ -363,10 +425,10 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     float* b = Bs + buf * BN * LDKT;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = (!FAST || a_ok[i]) ? a_st[i] : zero4;
+      *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = (!FAST || BUF || a_ok[i]) ? a_st[i] : zero4;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<f32x4*>(b + (r0 + RPP * i) * LDKT + k4) = (!FAST || b_ok[i]) ? b_st[i] : zero4;
+      *reinterpret_cast<f32x4*>(b + (r0 + RPP * i) * LDKT + k4) = (!FAST || BUF || b_ok[i]) ? b_st[i] : zero4;
   };
 
   f32x16 acc[TM][TN];
@@ -536,7 +598,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   }
 }
 
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST>
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
                             const float* mul, const GatherGeom& g, hipStream_t st) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
@@ -544,7 +606,7 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST>;
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -595,6 +657,15 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
     }
     const bool fast = (g.SC % 16 == 0) && variant != 3;
     if (fast) {
+      // buffer-descriptor path: 128 rows touch at most 128/(OHs*OWs) + 2 images; both footprints must fit 31 bits
+      static const bool buf_env = []() { const char* e = getenv("EDRL_GATHER_BUF"); return !(e && e[0] == '0'); }();
+      const long ohw = (long)g.OHs * g.OWs;
+      const bool buf = buf_env && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) &&
+                       (long)g.NC * g.Kfull * 4 < (1L << 31) && g.M < (1L << 31);
+      if (buf) {
+        if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 3, true, true>(src, wm, dst, bias, mul, g, st);
+        return launch_gather_v2<128, 128, DGRAD, 16, 3, true, true>(src, wm, dst, bias, mul, g, st);
+      }
       if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 3, true>(src, wm, dst, bias, mul, g, st);
       return launch_gather_v2<128, 128, DGRAD, 16, 3, true>(src, wm, dst, bias, mul, g, st);
     }
@@ -617,7 +688,11 @@ struct WgradGeom {
   int tiles_per_split;
 };
 
-template <int BM, int BN, bool VEC, int BKT, int OCC>
+// FASTLD (host-checked: VEC, 16/OW + 1 <= OH, per-block operand footprints < 2 GiB): both operands are fetched with
+// buffer loads through per-block descriptors whose range check zero-fills every out-of-range row, so the loop carries
+// no 64-bit address arithmetic, no zero-selects and no loops in the pixel decode: per staged row a 32-bit running
+// offset advanced by constants (one tile = BKT output pixels) with two branch-free wrap corrections.
+template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -666,8 +741,66 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) ap[i] = t_begin * BKT + (tid + 256 * i) / AC4;
   }
+  // ---- FASTLD state
+  constexpr unsigned OOB = 0x80000000u;         // offsets at/above 2 GiB stay outside every descriptor (ranges < 2 GiB)
+  unsigned a_off[A_LD], b_roff[B_LD];
+  int b_ih[B_LD], b_iw[B_LD];
+  int ih_lim = 0, iw_lim = 0, tapconst = 0;
+  unsigned a_step = 0, c_step = 0, c_wrapw = 0, c_wraph = 0;
+  int dw_step = 0, dh_step = 0;
+  __amdgpu_buffer_rsrc_t rs_dy, rs_x;
+  if constexpr (FASTLD) {
+    const long p_lo = t_begin * BKT;
+    long p_hi = t_end * BKT; if (p_hi > g.P) p_hi = g.P;
+    long rows = p_hi - p_lo; if (rows < 1) rows = 1;
+    const unsigned ld4y = (unsigned)(g.ld_dy * 4), ld4x = (unsigned)(g.ld_x * 4);
+    const unsigned dy_bytes = (unsigned)((rows - 1) * ld4y + (unsigned)g.Co * 4u);
+    rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p_lo * g.ld_dy), 0, (int)dy_bytes, 0x00020000);
+    const long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
+    const long imgs = n_hi - n_lo + 1;
+    const unsigned x_bytes = (unsigned)((imgs * g.SH * g.SW - 1) * ld4x + (unsigned)g.SC * 4u);
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + n_lo * g.SH * g.SW * g.ld_x), 0, (int)x_bytes, 0x00020000);
+    const int co = co0 + ac4 * 4;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      a_off[i] = co < g.Co ? (unsigned)((tid + 256 * i) / AC4) * ld4y + (unsigned)co * 4u : OOB;
+    a_step = BKT * ld4y;
+    const int a16 = BKT / g.OW, b16 = BKT - a16 * g.OW;
+    c_step = (unsigned)(b16 * g.stride + a16 * g.stride * g.SW) * ld4x;
+    c_wrapw = (unsigned)(g.stride * g.SW - g.OW * g.stride) * ld4x;
+    c_wraph = (unsigned)(g.SH * g.SW - g.OH * g.stride * g.SW) * ld4x;
+    dw_step = b16 * g.stride; dh_step = a16 * g.stride;
+    ih_lim = g.OH * g.stride + kkh - g.pad;
+    iw_lim = g.OW * g.stride + kkw - g.pad;
+    tapconst = ((kkh - g.pad) * g.SW + (kkw - g.pad)) * (int)ld4x + kc * 4;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      b_ih[i] = boh[i] * g.stride + kkh - g.pad;
+      b_iw[i] = bow[i] * g.stride + kkw - g.pad;
+      b_roff[i] = (unsigned)(((bn_[i] - (int)n_lo) * g.SH + boh[i] * g.stride) * g.SW + bow[i] * g.stride) * ld4x;
+    }
+  }
+  auto load_tile_fast = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_off[i], 0, 0));
+      a_off[i] += a_step;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const bool ok = kvalid && (unsigned)b_ih[i] < (unsigned)g.SH && (unsigned)b_iw[i] < (unsigned)g.SW;
+      const unsigned off = ok ? b_roff[i] + (unsigned)tapconst : OOB;
+      b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+      b_iw[i] += dw_step; b_ih[i] += dh_step; b_roff[i] += c_step;
+      const bool w = b_iw[i] >= iw_lim;
+      b_iw[i] -= w ? g.OW * g.stride : 0; b_ih[i] += w ? g.stride : 0; b_roff[i] += w ? c_wrapw : 0u;
+      const bool h = b_ih[i] >= ih_lim;
+      b_ih[i] -= h ? g.OH * g.stride : 0; b_roff[i] += h ? c_wraph : 0u;
+    }
+  };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_tile_vec = [&]() {   // loads the tile the running state points at, then advances the state by one tile
+    if constexpr (FASTLD) { load_tile_fast(); return; }
     const int co = co0 + ac4 * 4;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
@@ -844,11 +977,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 #define WG_BK 16
 #define WG_OCC 4
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, bool FASTLD = false>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st) {
   const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, WG_OCC>;
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, WG_OCC, FASTLD>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1002,8 +1135,18 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
   if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
   const bool vec = (Ci % 4 == 0) && (ld_x % 4 == 0) && (Co % 4 == 0) && (ld_dy % 4 == 0) &&
                    (((uintptr_t)dy & 15) == 0) && (((uintptr_t)x & 15) == 0);
+  // buffer-load path: decode wraps at most once per tile, per-block operand footprints addressable with 31 bits
+  static const bool fast_env = []() { const char* e = getenv("EDRL_WGRAD_FAST"); return !(e && e[0] == '0'); }();
+  const long span = (long)g.tiles_per_split * WG_BK;
+  const bool fast = vec && fast_env && (WG_BK / Wo + 1 <= Ho) && span * ld_dy * 4 < (1L << 31) &&
+                    (span / ((long)Ho * Wo) + 2) * Hi * Wi * ld_x * 4 < (1L << 31);
   int rc;
-  if (bm == 64 && bn == 64)
+  if (fast) {
+    if (bm == 64 && bn == 64) rc = launch_wgrad<64, 64, true, true>(dy, x, workspace, g, splits, st);
+    else if (bm == 64) rc = launch_wgrad<64, 128, true, true>(dy, x, workspace, g, splits, st);
+    else if (bn == 64) rc = launch_wgrad<128, 64, true, true>(dy, x, workspace, g, splits, st);
+    else rc = launch_wgrad<128, 128, true, true>(dy, x, workspace, g, splits, st);
+  } else if (bm == 64 && bn == 64)
     rc = vec ? launch_wgrad<64, 64, true>(dy, x, workspace, g, splits, st)
              : launch_wgrad<64, 64, false>(dy, x, workspace, g, splits, st);
   else if (bm == 64)

@@ -27,6 +27,9 @@ CONV_CASES = [
     (2, 128, 9, 9, 256, 1, 1, 0),    # 1x1
     (2, 256, 10, 10, 512, 1, 2, 0),  # 1x1 stride 2 (downsample)
     (1, 96, 7, 7, 200, 3, 1, 1),     # channel counts not multiples of the tile
+    (5, 32, 6, 6, 64, 3, 1, 1),      # wgrad buffer-load path: two row wraps + image wraps inside one 16-pixel tile
+    (3, 32, 4, 4, 64, 3, 1, 1),      # 16 pixels = one whole image: wgrad falls back to the generic decode
+    (7, 64, 12, 20, 64, 3, 2, 1),    # non-square, strided, pixel count not a multiple of the tile
 ]
 
 
