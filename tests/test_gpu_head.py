@@ -115,14 +115,19 @@ def test_bad_label_raises_like_reference(edrl, dev):
         m.forward_tokens(x[:1].to(dev), x1[:1].to(dev), y[:1].to(dev), to_dev(noise, dev))   # Q9: batch != args.batch_size
 
 
-def test_full_train_step_vs_oracle(edrl, dev):
-    """Row T1: two encoder forwards + head x2 + MK_MMD + backward + Adam on (B=2, R18, 64x64, S=4)."""
+@pytest.mark.parametrize("drop_oct_high", [False, True])
+def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high):
+    """Row T1: two encoder forwards + head x2 + MK_MMD + backward + Adam on (B=2, R18, 64x64, S=4); with
+    drop_oct_high the second view's OCT volume is all zeros (the missing-modality view of config C4,
+    data_harvard.py:333-334: every BatchNorm of that pass sees zero variance)."""
     from oracle import step_oracle as SO
     args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
     torch.manual_seed(0)
     m = edrl.MedFusion(2, 2, None, args).to(dev).train()
     orc = SO.OracleEDRL(m, dtype=torch.float64)
-    data, y = edrl.synthetic_batch(2, 64, 64, 4, device="cpu")
+    data, y = edrl.synthetic_batch(2, 64, 64, 4, device="cpu", drop_oct_high=drop_oct_high)
+    if drop_oct_high:
+        assert float(data[1][1].abs().max()) == 0.0
     N2, N3 = 4, 4
     n1, n2 = SO.make_noise(50, 2, N2, N3), SO.make_noise(51, 2, N2, N3)
     cast = lambda o: {k: cast(v) for k, v in o.items()} if isinstance(o, dict) else o.double()
@@ -160,3 +165,27 @@ def test_full_train_step_vs_oracle(edrl, dev):
     # Adam moved every parameter that has a gradient
     moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in m.named_parameters() if p.grad is not None)
     assert moved == sum(1 for p in m.parameters() if p.grad is not None)
+
+
+def test_train_step_bf16_encoders_tracks_fp32(edrl, dev):
+    """encoder_dtype="bf16" (C2/C4): same step with the bf16 MFMA trunks and the fp32 head.  The per-layer parity of
+    the bf16 trunk is in test_gpu_bf16.py; here the whole step must run, stay finite, give every live parameter a
+    gradient and land within bf16-storage distance of the fp32 step (loss 5 %, logits 0.1 absolute: B=2 BatchNorm)."""
+    outs = {}
+    for dt in ("fp32", "bf16"):
+        args = types.SimpleNamespace(mode="train", batch_size=4, encoder_depth=18, encoder_dtype=dt)
+        torch.manual_seed(0)
+        m = edrl.MedFusion(2, 2, None, args).to(dev).train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+        data, y = edrl.synthetic_batch(4, 96, 96, 6, device=dev, seed=7)
+        from oracle import step_oracle as SO
+        n1, n2 = SO.make_noise(60, 4, 9, 6), SO.make_noise(61, 4, 9, 6)
+        out = edrl.train_step(m, opt, data, y, noise1=to_dev(n1, dev), noise2=to_dev(n2, dev))
+        live = [p for p in m.parameters() if p.grad is not None]
+        assert all(torch.isfinite(p.grad).all() for p in live)
+        outs[dt] = (out["pred"].cpu(), float(out["loss"]), len(live))
+    assert outs["fp32"][2] == outs["bf16"][2]
+    dl = abs(outs["bf16"][1] - outs["fp32"][1]) / abs(outs["fp32"][1])
+    dp = float((outs["bf16"][0] - outs["fp32"][0]).abs().max())
+    print(f"[parity] bf16-encoder step vs fp32 step: loss rel diff {dl:.3e}, logits max abs diff {dp:.3e}")
+    assert dl < 5e-2 and dp < 0.1
