@@ -27,6 +27,9 @@ CONFIGS = {
     # BASELINE.json configs[2]; NOT the default bench line (the metric is quoted on C1/fp32): bf16 MFMA encoders
     # (bf16 activations/gradients, fp32 accumulate + fp32 BatchNorm statistics + fp32 weights/Adam), fp32 head.
     "C2": (64, 50, 224, 32, "bf16", "C2: B=64/GPU, ResNet-50 encoders on the bf16 MFMA path, 224x224 fundus + 32-slice OCT"),
+    # BASELINE.json configs[4] per-GPU shape (an 8-GPU config; B=3 is the largest per-GPU batch whose saved activations
+    # fit 288 GB): 512x512 fundus + 128-slice OCT, second view with the OCT volume dropped (zeros), bf16 encoders.
+    "C4": (3, 50, 512, 128, "bf16", "C4: B=3/GPU, ResNet-50 bf16 encoders, 512x512 fundus + 128-slice OCT, OCT-dropped second view"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense, 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
@@ -76,7 +79,7 @@ def main():
     edrl_amd.broadcast_parameters(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
     sync = edrl_amd.GradSync(model) if world > 1 else None
-    data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank)
+    data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank, drop_oct_high=(a.config == "C4"))
 
     def step():
         return edrl_amd.train_step(model, opt, data, y, grad_sync=sync.finish if sync else None)
