@@ -265,6 +265,7 @@ struct WgradGeomH {
   long P;
   int OH, OW, Co, SH, SW, SC, KH, KW, stride, pad, Ktot;
   int tiles_per_split;
+  int tiles_x, tiles_y;   // 1-D XCD-remapped grid: tiles_x * tiles_y * splits
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int pitch, int pix0, int col0, int lane) {
@@ -293,9 +294,15 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int co0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // the workgroups of one split stream the same pixel range: consecutive logical ids, one XCD (one L2)
+  const int lid = edrl_xcd_remap(blockIdx.x, gridDim.x);
+  const int per_split = g.tiles_x * g.tiles_y;
+  const int split = lid / per_split;
+  const int trem = lid - split * per_split;
+  const int tyi = trem / g.tiles_x;
+  const int co0 = tyi * BM, n0 = (trem - tyi * g.tiles_x) * BN;
   const long ptiles = (g.P + WBK - 1) / WBK;
-  const long t_begin = (long)blockIdx.z * g.tiles_per_split;
+  const long t_begin = (long)split * g.tiles_per_split;
   long t_end = t_begin + g.tiles_per_split;
   if (t_end > ptiles) t_end = ptiles;
 
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
       __syncthreads();
     }
   }
-  float* out = part + (long)blockIdx.z * g.Co * g.Ktot;
+  float* out = part + (long)split * g.Co * g.Ktot;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + li;
@@ -577,8 +584,10 @@ int edrl_conv2d_nhwc_wgrad_bf16(const void* dy, const void* x, float* dw, float*
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(edrl_cdiv(g.Ktot, BN), edrl_cdiv(Co, BM), splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const __bf16*)dy, (const __bf16*)x, workspace, g);
+  g.tiles_x = edrl_cdiv(g.Ktot, BN); g.tiles_y = edrl_cdiv(Co, BM);
+  const long nblk = (long)g.tiles_x * g.tiles_y * splits;
+  if (nblk > 0x7fffffffL) return EDRL_EINVAL;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy, (const __bf16*)x, workspace, g);
   EDRL_LAUNCH_CHECK();
   const long n = (long)Co * g.Ktot;
   hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n, splits, accumulate);

@@ -690,6 +690,7 @@ struct WgradGeom {
   int Ktot;         // KH*KW*SC columns of dW
   long ld_dy, ld_x;
   int tiles_per_split;
+  int tiles_x, tiles_y;   // dW tiles along K and Co: the grid is 1-D (tiles_x * tiles_y * splits), XCD-remapped
 };
 
 // FASTLD (host-checked: VEC, 16/OW + 1 <= OH, per-block operand footprints < 2 GiB): both operands are fetched with
@@ -710,8 +711,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int co0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int split = blockIdx.z;
+  // XCD-aware order: the tiles_x*tiles_y workgroups of one split (they all stream the same dY / X pixel range) get
+  // consecutive logical ids, and consecutive logical ids share an XCD, i.e. one L2 fetches that range once.
+  const int lid = edrl_xcd_remap(blockIdx.x, gridDim.x);
+  const int per_split = g.tiles_x * g.tiles_y;
+  const int split = lid / per_split;
+  const int trem = lid - split * per_split;
+  const int tyi = trem / g.tiles_x;
+  const int co0 = tyi * BM, n0 = (trem - tyi * g.tiles_x) * BN;
 
   const long ptiles = (g.P + BKT - 1) / BKT;
   const long t_begin = (long)split * g.tiles_per_split;
@@ -991,8 +998,11 @@ static int launch_wgrad(const float* dy, const float* x, float* part, const Wgra
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(edrl_cdiv(g.Ktot, BN), edrl_cdiv(g.Co, BM), splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dy, x, part, g);
+  WgradGeom gg = g;
+  gg.tiles_x = edrl_cdiv(g.Ktot, BN); gg.tiles_y = edrl_cdiv(g.Co, BM);
+  const long nblk = (long)gg.tiles_x * gg.tiles_y * splits;
+  if (nblk > 0x7fffffffL) return EDRL_EINVAL;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, x, part, gg);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

@@ -447,9 +447,35 @@ class ResNetTrunk(nn.Module):
         return getattr(self, name.replace(".", "__"))
 
     def bn_dict(self, name, p):
-        return {"weight": p[name + ".weight"], "bias": p[name + ".bias"],
-                "running_mean": self.get(name + ".running_mean"), "running_var": self.get(name + ".running_var"),
+        sc = getattr(self, "_scratch_running", None)
+        if sc is not None:      # a pass running concurrently with another one: see begin_scratch_running()
+            rm, rv = sc[name]
+        else:
+            rm, rv = self.get(name + ".running_mean"), self.get(name + ".running_var")
+        return {"weight": p[name + ".weight"], "bias": p[name + ".bias"], "running_mean": rm, "running_var": rv,
                 "momentum": 0.1, "eps": 1e-5}
+
+    # Two training passes that run CONCURRENTLY on two streams (train.train_step, EDRL_VIEW_STREAM=1) must still update
+    # the running statistics as if they had run one after the other (fusion_train.py:189-194: low view, then high
+    # view).  The update is linear, r <- (1-m) r + m s: the second pass accumulates m*s into zeroed scratch buffers and
+    # merge_scratch_running() folds them in after both passes have been joined: r <- (1-m) r_after_pass1 + m s2.
+    def begin_scratch_running(self):
+        bufs = getattr(self, "_scratch_bufs", None)
+        if bufs is None:
+            bufs = self._scratch_bufs = {n: (torch.zeros_like(self.get(n + ".running_mean")),
+                                             torch.zeros_like(self.get(n + ".running_var"))) for n in self._bn_names}
+        else:
+            torch._foreach_zero_([t for pair in bufs.values() for t in pair])
+        self._scratch_running = bufs
+
+    def end_scratch_running(self):
+        self._scratch_running = None
+
+    def merge_scratch_running(self):
+        bufs = self._scratch_bufs
+        run = [self.get(n + s) for n in self._bn_names for s in (".running_mean", ".running_var")]
+        torch._foreach_mul_(run, 0.9)
+        torch._foreach_add_(run, [t for n in self._bn_names for t in bufs[n]])
 
     def wgrad_stream(self):
         s = getattr(self, "_wgrad_stream", None)

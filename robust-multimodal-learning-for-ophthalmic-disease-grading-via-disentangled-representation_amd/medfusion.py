@@ -347,6 +347,15 @@ class MedFusion(nn.Module):
             loss = self.compute_loss_train(loss1, kl_f, kl_o, pl_f, pl_o, loss_DILR)
         return pred, loss, combine_features
 
+    def trunks(self):
+        return (self.transformer_2DNet.trunk, self.transformer_3DNet.trunk)
+
+    def encode(self, X):
+        """Encoder stage only (fusion_net.py:884-885): -> (fundus tokens [B,N2,1024], OCT tokens [B,N3,768])."""
+        x, _ = self.transformer_2DNet(X[0])
+        x1, _ = self.transformer_3DNet(X[1])
+        return x, x1
+
     def forward(self, X, y, epoch=None, noise=None):
         self.check_labels(y)
         if _FUNDUS_SIDE_STREAM and X[0].is_cuda:

@@ -6,6 +6,8 @@ Call order reproduced exactly (fusion_train.py:189-224):
 The per-iteration host syncs of the reference (`.cpu()`, `.item()`, fusion_train.py:214-225) are
 not part of the contract: metrics stay on the device and are pulled by the caller.
 """
+import os
+
 import torch
 
 from . import ops
@@ -37,13 +39,57 @@ def device_twin_views(fundus_low, oct_low, sigma=0.5, drop_oct_high=False):
     return [fundus_low, oct_low], [f_high, o_high]
 
 
+# EDRL_VIEW_STREAM=1: overlap the two views' encoder passes on two HIP streams (see train_step).
+_VIEW_STREAM = os.environ.get("EDRL_VIEW_STREAM", "0") == "1"
+_view_stream = None
+
+
+def set_view_overlap(on):
+    """Switch the two-stream execution of the two views' encoder passes (same results; see train_step)."""
+    global _VIEW_STREAM
+    _VIEW_STREAM = bool(on)
+    if on:   # the shared parameters' AccumulateGrad nodes see gradients from two streams: intentional
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
+if _VIEW_STREAM:
+    set_view_overlap(True)
+
+
 def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None, grad_sync=None):
     """One iteration of the loop body at fusion_train.py:176-225. Returns device tensors, no host sync.
     `grad_sync` (optional): called after backward, before optimizer.step (DP gradient all-reduce)."""
     data1, data2 = data
     optimizer.zero_grad()
-    pred, loss, combined_features1 = model(data1, target, epoch, noise=noise1)
-    _, _, combined_features2 = model(data2, target, epoch, noise=noise2)
+    if _VIEW_STREAM and target.is_cuda and model.training:
+        # The two views' encoder passes are independent (they meet in MK_MMD): the second one runs on a side stream so
+        # that its HBM-bound BatchNorm kernels overlap the first one's MFMA-bound convolutions and vice versa; autograd
+        # replays the same streams in backward.  The head (stateful DILR.bn1/bn2, 4 updates per step) stays in order
+        # on the main stream; the encoders' running statistics are merged in order (ResNetTrunk.merge_scratch_running).
+        global _view_stream
+        main = torch.cuda.current_stream()
+        if _view_stream is None:
+            _view_stream = torch.cuda.Stream()
+        side = _view_stream
+        side.wait_stream(main)
+        model.check_labels(target)
+        tok1 = model.encode(data1)
+        with torch.cuda.stream(side):
+            for t in model.trunks():
+                t.begin_scratch_running()
+            tok2 = model.encode(data2)
+            for t in model.trunks():
+                t.end_scratch_running()
+        pred, loss, combined_features1 = model.forward_tokens(tok1[0], tok1[1], target, noise1)
+        main.wait_stream(side)
+        for t in model.trunks():
+            t.merge_scratch_running()
+        for t in tok2:
+            t.record_stream(main)
+        _, _, combined_features2 = model.forward_tokens(tok2[0], tok2[1], target, noise2)
+    else:
+        pred, loss, combined_features1 = model(data1, target, epoch, noise=noise1)
+        _, _, combined_features2 = model(data2, target, epoch, noise=noise2)
     loss_MDD = MK_MMD(combined_features1, combined_features2)
     total = ops.scalar_mix([1.0, 1.0], [loss, loss_MDD])
     predicted = ops.argmax_rows(pred)

@@ -189,3 +189,41 @@ def test_train_step_bf16_encoders_tracks_fp32(edrl, dev):
     dp = float((outs["bf16"][0] - outs["fp32"][0]).abs().max())
     print(f"[parity] bf16-encoder step vs fp32 step: loss rel diff {dl:.3e}, logits max abs diff {dp:.3e}")
     assert dl < 5e-2 and dp < 0.1
+
+
+def test_view_overlap_streams_same_results(edrl, dev):
+    """edrl_amd.set_view_overlap(True): the second view's encoder passes run on a side stream (and autograd replays
+    that in backward).  Same kernels, same inputs: logits, losses and every gradient must be BIT-identical to the
+    in-order step; the encoders' running statistics go through the scratch-and-merge path and must agree to 1e-6."""
+    from oracle import step_oracle as SO
+    res = {}
+    for mode in (False, True):
+        args = types.SimpleNamespace(mode="train", batch_size=4, encoder_depth=18)
+        torch.manual_seed(0)
+        m = edrl.MedFusion(2, 2, None, args).to(dev).train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+        data, y = edrl.synthetic_batch(4, 96, 96, 6, device=dev, seed=11)
+        n1, n2 = SO.make_noise(70, 4, 9, 6), SO.make_noise(71, 4, 9, 6)
+        edrl.set_view_overlap(mode)
+        try:
+            for _ in range(2):      # two steps: the second one reuses (re-zeroes) the scratch buffers
+                out = edrl.train_step(m, opt, data, y, noise1=to_dev(n1, dev), noise2=to_dev(n2, dev))
+        finally:
+            edrl.set_view_overlap(False)
+        torch.cuda.synchronize()
+        res[mode] = (out, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
+                     {n: b.clone() for n, b in m.named_buffers()})
+    a, b = res[False], res[True]
+    for k in ("pred", "loss", "loss_MDD"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert a[1].keys() == b[1].keys()
+    for n in a[1]:
+        assert torch.equal(a[1][n], b[1][n]), f"grad {n}"
+    worst = 0.0
+    for n in a[2]:
+        if a[2][n].dtype.is_floating_point:
+            worst = max(worst, float((a[2][n] - b[2][n]).abs().max() / a[2][n].abs().max().clamp_min(1e-30)))
+        else:
+            assert torch.equal(a[2][n], b[2][n]), n
+    print(f"[parity] view overlap: outputs and {len(a[1])} gradients bit-identical; running statistics max rel diff {worst:.2e}")
+    assert worst < 1e-6
