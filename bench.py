@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of edrl_amd.FusedAdam")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra timed region with the two views overlapped")
     a = ap.parse_args()
 
@@ -78,7 +79,8 @@ def main():
     torch.manual_seed(0)
     model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
     edrl_amd.broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    # the reference's optim.Adam(lr, weight_decay=1e-6) (fusion_train.py:747) as one multi-tensor launch; --torch-adam: stock
+    opt = (torch.optim.Adam if a.torch_adam else edrl_amd.FusedAdam)(model.parameters(), lr=1e-4, weight_decay=1e-6)
     sync = edrl_amd.GradSync(model) if world > 1 else None
     data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank, drop_oct_high=(a.config == "C4"))
 
@@ -142,7 +144,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": enc_dtype, "data": "synthetic",
             "config": {"workload": desc, "global_batch": B * world, "per_gpu_batch": B, "encoder": f"resnet{depth}",
                        "fundus": [3, HW, HW], "oct": [1, S, HW, HW], "parallelism": f"dp{world}",
-                       "optimizer": "Adam(lr=1e-4, weight_decay=1e-6)"},
+                       "optimizer": ("torch.optim.Adam" if a.torch_adam else "FusedAdam") + "(lr=1e-4, weight_decay=1e-6)"},
             "final_loss": loss,
             "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }

@@ -260,6 +260,15 @@ int edrl_mk_mmd_fwd_f32(const float* G, const float* sq, int n, int ns, float ke
 int edrl_mk_mmd_bwd_f32(const float* dloss, const float* G, const float* sq, const float* saved, int n, int ns,
                         float kernel_mul, int kernel_num, float* workspace, float* coef, hipStream_t stream);
 
+/* ---- optimiser (optim.hip) -------------------------------------------------------------------------------------
+ * Fused multi-tensor Adam: replaces `optimizer.step()` of torch.optim.Adam(model.parameters(), lr, weight_decay=1e-6)
+ * (fusion_train.py:224, :747).  tensors: device array of {float* p; const float* g; float* m;
+ * float* v; long n} records; chunks: device array of {int tensor; int chunk} records, edrl_adam_chunk_elems() elements
+ * per chunk; step = the step count after this update (>= 1). */
+int edrl_adam_chunk_elems(void);
+int edrl_adam_multi_f32(const void* tensors, int n_tensors, const void* chunks, int n_chunks, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, long step, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

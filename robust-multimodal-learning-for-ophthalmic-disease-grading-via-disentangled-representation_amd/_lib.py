@@ -35,6 +35,8 @@ def parse_header(path=HEADER_PATH):
         argtypes = []
         for a in args.split(","):
             a = a.strip()
+            if a in ("", "void"):
+                continue
             if "*" in a:
                 argtypes.append(ctypes.c_void_p)
             else:

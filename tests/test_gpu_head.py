@@ -227,3 +227,29 @@ def test_view_overlap_streams_same_results(edrl, dev):
             assert torch.equal(a[2][n], b[2][n]), n
     print(f"[parity] view overlap: outputs and {len(a[1])} gradients bit-identical; running statistics max rel diff {worst:.2e}")
     assert worst < 1e-6
+
+
+def test_fused_adam_step_matches_torch_adam_on_model(edrl, dev):
+    """One full train_step with edrl.FusedAdam vs torch.optim.Adam from identical weights / data / noise: bit-identical
+    gradients, so every parameter must land within 1e-6 (relative to the tensor's max) of the stock optimiser's.
+    (One step only: parameters whose true gradient is zero -- e.g. biases in front of a batch normalisation -- receive
+    pure rounding noise, which Adam's normalisation turns into +-lr steps; from the second step on such parameters
+    differ by O(lr) between ANY two implementations, the stock one run twice on different hardware included.)"""
+    from oracle import step_oracle as SO
+    res = {}
+    for name in ("torch", "fused"):
+        args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
+        torch.manual_seed(0)
+        m = edrl.MedFusion(2, 2, None, args).to(dev).train()
+        opt = (torch.optim.Adam if name == "torch" else edrl.FusedAdam)(m.parameters(), lr=1e-4, weight_decay=1e-6)
+        data, y = edrl.synthetic_batch(2, 64, 64, 4, device=dev, seed=3)
+        n1, n2 = SO.make_noise(80, 2, 4, 4), SO.make_noise(81, 2, 4, 4)
+        edrl.train_step(m, opt, data, y, noise1=to_dev(n1, dev), noise2=to_dev(n2, dev))
+        res[name] = {n: p.detach().clone() for n, p in m.named_parameters()}
+    worst, wn = 0.0, ""
+    for n, a in res["torch"].items():
+        e = float((a - res["fused"][n]).abs().max() / a.abs().max().clamp_min(1e-30))
+        if e > worst:
+            worst, wn = e, n
+    print(f"[parity] FusedAdam vs torch Adam after one model step: worst rel diff {worst:.3e} ({wn})")
+    assert worst < 1e-6

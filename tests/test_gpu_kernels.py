@@ -385,3 +385,31 @@ def test_conv_fused_bn_statistics(edrl, dev, case):
     check(f"fused_mean{case}", outs[0].cpu(), yd.mean(0), 1e-5)
     check(f"fused_rstd{case}", outs[1].cpu(), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-5)
     check("fused_running_var", rv.cpu(), 0.9 + 0.1 * yd.var(0, unbiased=True), 1e-5)
+
+
+def test_fused_adam_vs_torch_adam(edrl, dev):
+    """edrl_adam_multi_f32 (one launch for all tensors) against torch.optim.Adam(lr, weight_decay=1e-6) of
+    fusion_train.py:747 over 5 steps: odd sizes, a tensor larger than one chunk, one parameter that never gets a
+    gradient.  Same update rule, different rounding points (one fused expression vs 7 foreach passes): parameters and
+    moments within 2e-6 of their max; state_dict round-trips into torch.optim.Adam."""
+    torch.manual_seed(0)
+    shapes = [(3,), (17, 5), (64, 3, 3, 16), (40000,), (1,), (129, 257)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes] + [torch.nn.Parameter(torch.randn(7, device=dev))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = edrl.FusedAdam(pa, lr=1e-2, weight_decay=1e-6)
+    ob = torch.optim.Adam(pb, lr=1e-2, weight_decay=1e-6)
+    for it in range(5):
+        for x, y in zip(pa[:-1], pb[:-1]):
+            g = torch.randn_like(x) * (10.0 ** (it - 2))
+            x.grad = g.clone(); y.grad = g.clone()
+        oa.step(); ob.step()
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        check(f"adam.param[{i}]", x.detach().cpu(), y.detach().cpu(), 2e-6)
+    assert torch.equal(pa[-1].detach(), pb[-1].detach()) and pa[-1] not in oa.state
+    for x, y in zip(pa[:-1], pb[:-1]):
+        check("adam.exp_avg", oa.state[x]["exp_avg"].cpu(), ob.state[y]["exp_avg"].cpu(), 2e-6)
+        check("adam.exp_avg_sq", oa.state[x]["exp_avg_sq"].cpu(), ob.state[y]["exp_avg_sq"].cpu(), 2e-6)
+        assert float(oa.state[x]["step"]) == float(ob.state[y]["step"]) == 5.0
+    oc = torch.optim.Adam(pb, lr=1e-2, weight_decay=1e-6)
+    oc.load_state_dict(oa.state_dict())           # checkpoint interchange with the stock optimiser
+    assert float(oc.state[pb[0]]["step"]) == 5.0
