@@ -9,6 +9,7 @@
 // (a K tile never straddles a tap), which holds for every conv of the ResNet trunks except the stem; the stem and
 // the weight gradient stay on the fp32 kernels (conv_gemm.hip) in round 1.
 #include "edrl_common.h"
+#include <stdlib.h>
 #include "conv_geom.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -17,7 +18,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define HBK 32            // K tile in bf16 elements
 #define HLD (HBK + 8)     // padded LDS row (elements): 80 bytes
 
-template <int BN, bool DGRAD>
+typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+
+// BUF: operand loads through buffer descriptors exactly as in conv_gemm.hip's fp32 kernel (masked rows / taps are an
+// out-of-range offset the hardware zero-fills; one add per staged piece and tile).
+template <int BN, bool DGRAD, bool BUF = false>
 __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* __restrict__ src,
                                                                   const __bf16* __restrict__ wm,
                                                                   __bf16* __restrict__ dst, GatherGeom g, int tiles_n) {
@@ -65,9 +70,47 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
   int c = k8, ta = 0, tb = 0, kk = k8;
   long rowoff[A_LD];
   long tapoff = 0;
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned aoff[A_LD], boff[B_LD], wrow2[B_LD];
+  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  int n_first = 0, cb = 0;
+  if constexpr (BUF) {
+    const int ohw = g.OHs * g.OWs;
+    long mlast = m0 + BM; if (mlast > g.M) mlast = g.M;
+    n_first = (int)(m0 / ohw);
+    const int n_last = (int)((mlast - 1) / ohw);
+    const unsigned a_bytes = (unsigned)(((long)(n_last - n_first + 1) * g.SH * g.SW - 1) * g.ld_src * 2 + (long)g.SC * 2);
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
+    rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, (int)((long)g.NC * g.Kfull * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int n = n0 + r0 + 64 * i;
+      wrow2[i] = n < g.NC ? (unsigned)n * (unsigned)g.Kfull * 2u : OOB;
+    }
+  }
   auto retap = [&]() {
     const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
     tapoff = (long)(kh * g.KW + kw) * g.SC;
+    if constexpr (BUF) {
+      const bool kvalid = ta < g.KHs && g.KWs > 0;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int sh, sw;
+        bool ok = kvalid && rn[i] >= 0;
+        if (DGRAD) {
+          const int th = rh[i] - kh, tw = rw[i] - kw;
+          ok = ok && th >= 0 && tw >= 0;
+          sh = th >> g.sshift; sw = tw >> g.sshift;
+        } else { sh = rh[i] + kh; sw = rw[i] + kw; }
+        ok = ok && (unsigned)sh < (unsigned)g.SH && (unsigned)sw < (unsigned)g.SW;
+        const unsigned pix = (unsigned)(((rn[i] - n_first) * g.SH + sh) * g.SW + sw);
+        aoff[i] = ok ? pix * (unsigned)(g.ld_src * 2) + (unsigned)(cb + k8) * 2u : OOB;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        boff[i] = kvalid ? wrow2[i] + (unsigned)((int)tapoff + cb + k8) * 2u : OOB;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       int sh, sw;
@@ -83,6 +126,17 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
   };
   retap();
   auto advance = [&]() {
+    if constexpr (BUF) {
+      cb += HBK;
+      if (cb >= g.SC) { cb -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
+      else {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) aoff[i] += HBK * 2;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) boff[i] += HBK * 2;
+      }
+      return;
+    }
     c += HBK; kk += HBK;
     if (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
   };
@@ -93,6 +147,15 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
   auto load_tile = [&]() {
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        a_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)aoff[i], 0, 0));
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        b_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)boff[i], 0, 0));
+      return;
+    }
     const bool kvalid = kk < g.Ktot;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
@@ -112,10 +175,10 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
     __bf16* b = Bs + buf * BN * HLD;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<bf16x8*>(a + (r0 + 64 * i) * HLD + k8) = a_ok[i] ? a_st[i] : zero8;
+      *reinterpret_cast<bf16x8*>(a + (r0 + 64 * i) * HLD + k8) = (BUF || a_ok[i]) ? a_st[i] : zero8;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<bf16x8*>(b + (r0 + 64 * i) * HLD + k8) = b_ok[i] ? b_st[i] : zero8;
+      *reinterpret_cast<bf16x8*>(b + (r0 + 64 * i) * HLD + k8) = (BUF || b_ok[i]) ? b_st[i] : zero8;
   };
 
   f32x16 acc[TM][TN];
@@ -230,8 +293,8 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
   }
 }
 
-template <int BN, bool DGRAD>
-static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st) {
+template <int BN, bool DGRAD, bool BUF>
+static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st) {
   const int tiles_m = edrl_cdiv(g.M, 128), tiles_n = edrl_cdiv(g.NC, BN);
   const long nblk = (long)tiles_m * tiles_n;
   if (nblk <= 0) return 0;
@@ -239,7 +302,7 @@ static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, 
   size_t lds = (size_t)2 * (128 + BN) * HLD * sizeof(__bf16);
   const size_t epi = (size_t)(4 * 32 * (BN / 2 + 4) + 4 * 2 * (BN / 2)) * sizeof(float);
   if (epi > lds) lds = epi;
-  auto kern = conv_gather_bf16_kernel<BN, DGRAD>;
+  auto kern = conv_gather_bf16_kernel<BN, DGRAD, BUF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -248,6 +311,16 @@ static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, 
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, g, tiles_n);
   EDRL_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BN, bool DGRAD>
+static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st) {
+  static const bool buf_env = []() { const char* e = getenv("EDRL_GATHER_BUF"); return !(e && e[0] == '0'); }();
+  const long ohw = (long)g.OHs * g.OWs;
+  const bool buf = buf_env && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 2 < (1L << 31) &&
+                   (long)g.NC * g.Kfull * 2 < (1L << 31) && g.M < (1L << 31);
+  if (buf) return launch_gather_bf16_impl<BN, DGRAD, true>(src, wm, dst, g, st);
+  return launch_gather_bf16_impl<BN, DGRAD, false>(src, wm, dst, g, st);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient (bf16)
