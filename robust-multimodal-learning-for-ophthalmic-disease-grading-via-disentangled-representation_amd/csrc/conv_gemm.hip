@@ -1007,16 +1007,22 @@ static int launch_wgrad(const float* dy, const float* x, float* part, const Wgra
   return 0;
 }
 
-static void wgrad_plan(long P, int Co, int Ktot, int* bm, int* bn, int* splits, int* tiles_per_split) {
+static void wgrad_plan(long P, int Co, int Ktot, int taps, int* bm, int* bn, int* splits, int* tiles_per_split) {
   *bm = Co <= 64 ? 64 : 128;
   *bn = Ktot <= 64 ? 64 : 128;
   const long tiles = (long)edrl_cdiv(Co, *bm) * edrl_cdiv(Ktot, *bn);
   const long ptiles = (P + WG_BK - 1) / WG_BK;
-  long want = (1536 + tiles - 1) / tiles;          // ~6 blocks per CU in flight
+  // Workgroups per launch (1024 are resident: 256 CUs x 4).  Measured on the ResNet-50 shapes (profiles/): multi-tap
+  // convs gain 5-15 % from 3 rounds of shorter pixel ranges (the taps' re-reads of X stay in L2), 1x1 convs are best
+  // at 1.5 rounds (fewer partial slabs to reduce).
+  static const long target_env = []() { const char* e = getenv("EDRL_WGRAD_TARGET"); return e ? atol(e) : 0L; }();
+  const long target = target_env > 0 ? target_env : (taps > 1 ? 3072L : 1536L);
+  long want = target / tiles;                       // floor: just under a whole number of rounds, never just over
+  if (want < 1) want = 1;
   long max_by_len = ptiles / 16; if (max_by_len < 1) max_by_len = 1;  // >= 16 K tiles per split
   long s = want < max_by_len ? want : max_by_len;
   if (s < 1) s = 1;
-  if (s > 512) s = 512;
+  if (s > 1024) s = 1024;
   long tps = (ptiles + s - 1) / s;
   s = (ptiles + tps - 1) / tps;
   if (s < 1) s = 1;
@@ -1126,7 +1132,7 @@ int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int 
 
 size_t edrl_conv2d_nhwc_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW) {
   int bm, bn, splits, tps;
-  wgrad_plan((long)N * Ho * Wo, Co, KH * KW * Ci, &bm, &bn, &splits, &tps);
+  wgrad_plan((long)N * Ho * Wo, Co, KH * KW * Ci, KH * KW, &bm, &bn, &splits, &tps);
   return (size_t)splits * Co * KH * KW * Ci * sizeof(float);
 }
 
@@ -1144,7 +1150,7 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
   g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
   g.ld_dy = ld_dy; g.ld_x = ld_x;
   int bm, bn, splits;
-  wgrad_plan(g.P, Co, g.Ktot, &bm, &bn, &splits, &g.tiles_per_split);
+  wgrad_plan(g.P, Co, g.Ktot, KH * KW, &bm, &bn, &splits, &g.tiles_per_split);
   const size_t need = (size_t)splits * Co * g.Ktot * sizeof(float);
   if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
   const bool vec = (Ci % 4 == 0) && (ld_x % 4 == 0) && (Co % 4 == 0) && (ld_dy % 4 == 0) &&
