@@ -516,11 +516,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_h_kernel(const float* __res
 static void wgrad_plan_h(long P, int Co, int Ktot, int* splits, int* tiles_per_split) {
   const long tiles = (long)edrl_cdiv(Co, 128) * edrl_cdiv(Ktot, 128);
   const long ptiles = (P + WBK - 1) / WBK;
-  long want = (1536 + tiles - 1) / tiles;
+  // 768 workgroups are resident (256 CUs x 3): aim just under a whole number of rounds (see conv_gemm.hip wgrad_plan)
+  static const long target = []() { const char* e = getenv("EDRL_WGRAD_TARGET_BF16"); return e ? atol(e) : 1536L; }();
+  long want = target / tiles;
+  if (want < 1) want = 1;
   long max_by_len = ptiles / 16; if (max_by_len < 1) max_by_len = 1;
   long s = want < max_by_len ? want : max_by_len;
   if (s < 1) s = 1;
-  if (s > 512) s = 512;
+  if (s > 1024) s = 1024;
   long tps = (ptiles + s - 1) / s;
   s = (ptiles + tps - 1) / tps;
   *splits = (int)(s < 1 ? 1 : s);
