@@ -246,6 +246,10 @@ int edrl_bn_eval_params_f32(const float* gamma, const float* beta, const float* 
 /* ---- SURVEY §8(f) rows 3-4 ---- */
 /* out = clip(x + sigma*noise, 0, 1): the high-noise twin view of data_harvard.py:769-783 made on the device. */
 int edrl_twin_view_f32(const float* x, const float* noise, float* out, long n, float sigma, hipStream_t stream);
+/* Salt-and-pepper (add_salt_peper / add_salt_peper_3D, data_harvard.py:24-48): x[img,:,rows[img][j],cols[img][j]] = value,
+ * x NCHW [n_img,C,H,W] in place, rows/cols int32 [n_img][n_pts] drawn by the caller; out-of-range points are ignored. */
+int edrl_scatter_fill_nchw_f32(float* x, const int* rows, const int* cols, int n_img, long n_pts, int C, int H, int W,
+                               float value, hipStream_t stream);
 /* compute_kl_divergence(p, m) = mean_b sum_c p log(p/m) (code/MMD.py:92-95; compute_js_divergence :76-90 composes it). */
 int edrl_kl_rows_fwd_f32(const float* p, const float* m, float* out, int B, int C, hipStream_t stream);
 int edrl_kl_rows_bwd_f32(const float* dloss, const float* p, const float* m, float* dp, float* dm, int B, int C,

@@ -11,10 +11,10 @@ from . import _lib, ops
 from .mmd import MK_MMD, compute_js_divergence, compute_kl_divergence
 from .medfusion import MedFusion, EPRL, PoE, DILR, AttentionModel, off_diagonal
 from .encoders import ResNetTrunk, FundusEncoder, OCTSliceEncoder
-from .train import train_step, train, val, synthetic_batch, device_twin_views, set_view_overlap
+from .train import train_step, train, val, synthetic_batch, device_twin_views, set_view_overlap, DevicePrefetcher
 from .dist import GradSync, broadcast_parameters
 from .optim import FusedAdam
 
 __all__ = ["MedFusion", "EPRL", "PoE", "DILR", "AttentionModel", "off_diagonal", "MK_MMD", "compute_js_divergence", "compute_kl_divergence", "ResNetTrunk",
-           "FundusEncoder", "OCTSliceEncoder", "train_step", "train", "val", "synthetic_batch", "device_twin_views", "set_view_overlap", "ops", "GradSync",
+           "FundusEncoder", "OCTSliceEncoder", "train_step", "train", "val", "synthetic_batch", "device_twin_views", "set_view_overlap", "DevicePrefetcher", "ops", "GradSync",
            "broadcast_parameters", "FusedAdam"]

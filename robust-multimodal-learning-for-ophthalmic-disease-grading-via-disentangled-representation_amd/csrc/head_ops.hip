@@ -582,6 +582,22 @@ __global__ void argmax_rows_kernel(const float* __restrict__ x, long long* __res
 
 // ------------------------------------------------------------------ twin-view noise, KL/JS of soft labels
 // out = clip(x + sigma * noise, 0, 1)   — the Gaussian high-noise view of data_harvard.py:769-783 on the device
+// Salt-and-pepper noise (data_harvard.py:24-48): x[img, :, rows[img][j], cols[img][j]] = value for j < n_pts.
+// The coordinates are INPUTS (drawn by the caller's RNG, as the reference draws them with numpy), so the result is
+// bit-exact; duplicates write the same value, salt (1) is launched before pepper (0) as in the reference.
+__global__ __launch_bounds__(256) void scatter_fill_nchw_kernel(float* __restrict__ x, const int* __restrict__ rows,
+                                                                const int* __restrict__ cols, int n_img, long n_pts,
+                                                                int C, int H, int W, float value) {
+  const long total = (long)n_img * n_pts;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int img = (int)(i / n_pts);
+    const int r = rows[i], c = cols[i];
+    if ((unsigned)r >= (unsigned)H || (unsigned)c >= (unsigned)W) continue;
+    float* base = x + ((long)img * C * H + r) * W + c;
+    for (int ch = 0; ch < C; ++ch) base[(long)ch * H * W] = value;
+  }
+}
+
 __global__ __launch_bounds__(256) void twin_view_kernel(const float* __restrict__ x, const float* __restrict__ noise,
                                                         float* __restrict__ out, long n, float sigma) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -681,6 +697,15 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const flo
 
 extern "C" {
 
+int edrl_scatter_fill_nchw_f32(float* x, const int* rows, const int* cols, int n_img, long n_pts, int C, int H, int W,
+                               float value, hipStream_t st) {
+  if (n_img <= 0 || n_pts < 0 || C <= 0 || H <= 0 || W <= 0) return EDRL_EINVAL;
+  if (n_pts == 0) return 0;
+  hipLaunchKernelGGL(scatter_fill_nchw_kernel, dim3(ew_grid((long)n_img * n_pts)), dim3(256), 0, st, x, rows, cols, n_img, n_pts,
+                     C, H, W, value);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
 int edrl_twin_view_f32(const float* x, const float* noise, float* out, long n, float sigma, hipStream_t st) {
   if (n <= 0) return EDRL_EINVAL;
   hipLaunchKernelGGL(twin_view_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, noise, out, n, sigma);

@@ -815,6 +815,26 @@ def twin_view(x, sigma=0.5, noise=None):
     return out
 
 
+def salt_pepper_(x, amount, coords=None, generator=None):
+    """In-place salt-and-pepper noise on an NCHW batch [N,C,H,W] (OCT volumes: pass the [B*S,1,H,W] slice view), the
+    device form of add_salt_peper / add_salt_peper_3D (data_harvard.py:24-48): ceil(amount*H*W*0.5) salt points set
+    to 1 on every channel, then as many pepper points set to 0, coordinates uniform in [0, H-1) x [0, W-1) (numpy
+    randint's exclusive upper bound i-1, reproduced).  `coords` = (salt_rows, salt_cols, pepper_rows, pepper_cols)
+    int32 [N, n] lets the caller supply the draws (parity tests); otherwise they are drawn with torch on the device."""
+    x = _chk(x, "salt_pepper.x", False)
+    if not x.is_contiguous() or x.dim() != 4:
+        raise RuntimeError("salt_pepper_: contiguous [N,C,H,W] expected")
+    N, C, H, W = x.shape
+    n = int(-(-amount * H * W * 0.5 // 1))
+    if coords is None:
+        draw = lambda hi: torch.randint(0, max(hi - 1, 1), (N, n), device=x.device, dtype=torch.int32, generator=generator)
+        coords = (draw(H), draw(W), draw(H), draw(W))
+    sr, sc, pr, pc = [c.to(device=x.device, dtype=torch.int32).contiguous() for c in coords]
+    L.call("edrl_scatter_fill_nchw_f32", P(x), P(sr), P(sc), N, sr.shape[1], C, H, W, 1.0)
+    L.call("edrl_scatter_fill_nchw_f32", P(x), P(pr), P(pc), N, pr.shape[1], C, H, W, 0.0)
+    return x
+
+
 # ------------------------------------------------------------------ bf16 contractions (C2/C4 precision; raw helpers)
 def to_bf16(x):
     x = _chk(x, "to_bf16.x", False).contiguous()

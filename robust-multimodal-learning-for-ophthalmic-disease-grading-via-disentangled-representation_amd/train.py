@@ -56,6 +56,59 @@ if _VIEW_STREAM:
     set_view_overlap(True)
 
 
+class DevicePrefetcher:
+    """H2D side of SURVEY.md §8(f) row 3: wraps a loader of (X, y) batches with X = [fundus [B,3,H,W], oct [B,1,S,H,W]]
+    host tensors, stages each batch through pinned buffers and copies it on a side stream one batch ahead of the
+    consumer (the reference does a synchronous `.cuda()` per tensor, fusion_train.py:181-184), then builds the twin
+    views on the device (device_twin_views: Gaussian + clip, optional OCT drop, optional salt-and-pepper).
+    Yields ((low_views, high_views), y) ready for train_step."""
+
+    def __init__(self, loader, device, sigma=0.5, drop_oct_high=False, salt_pepper=0.0):
+        self.loader, self.device = loader, torch.device(device)
+        self.sigma, self.drop, self.sp = sigma, drop_oct_high, salt_pepper
+        self.stream = torch.cuda.Stream(self.device)
+        self._pinned = {}
+
+    def _stage(self, key, t):
+        buf = self._pinned.get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = self._pinned[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        buf.copy_(t)
+        return buf
+
+    def _upload(self, batch, slot):
+        X, y = batch
+        with torch.cuda.stream(self.stream):
+            dev = [self._stage((slot, i), t).to(self.device, non_blocking=True) for i, t in enumerate(X)]
+            yd = self._stage((slot, "y"), y).to(self.device, non_blocking=True)
+        return dev, yd
+
+    def __iter__(self):
+        it = iter(self.loader)
+        nxt, slot = None, 0
+        try:
+            nxt = self._upload(next(it), slot)
+        except StopIteration:
+            return
+        while nxt is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            (fundus, oct_), y = nxt
+            for t in (fundus, oct_, y):
+                t.record_stream(torch.cuda.current_stream())
+            slot ^= 1                       # the other pinned set: the copy that was just consumed may still be read
+            try:
+                nxt = self._upload(next(it), slot)
+            except StopIteration:
+                nxt = None
+            low, high = device_twin_views(fundus, oct_, self.sigma, self.drop)
+            if self.sp > 0:
+                ops.salt_pepper_(high[0], self.sp)
+                if not self.drop:
+                    B, C, S, H, W = high[1].shape
+                    ops.salt_pepper_(high[1].view(B * S, C, H, W), self.sp)
+            yield (low, high), y
+
+
 def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None, grad_sync=None):
     """One iteration of the loop body at fusion_train.py:176-225. Returns device tensors, no host sync.
     `grad_sync` (optional): called after backward, before optimizer.step (DP gradient all-reduce)."""

@@ -108,3 +108,44 @@ def test_js_divergence_and_twin_view(edrl, dev):
     out = edrl.ops.twin_view(x.to(dev), 0.5, n.to(dev))
     check("twin_view", out.cpu(), (x.double() + 0.5 * n.double()).clamp(0, 1), 1e-6)
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+
+
+def test_salt_pepper_bit_exact_and_prefetcher(edrl, dev):
+    """§8(f) row 3.  (1) salt-and-pepper scatter vs a numpy restatement of add_salt_peper (data_harvard.py:35-48:
+    HWC image, salt then pepper, all channels) and add_salt_peper_3D (:24-33, per OCT slice) on the same coordinate
+    draws: BIT-exact.  (2) DevicePrefetcher: pinned-buffer / side-stream upload one batch ahead yields exactly the
+    loader's batches (low views bit-identical), twin views within [0,1], OCT-drop gives zeros, and feeds train()."""
+    import numpy as np
+    rng = np.random.RandomState(0)
+    N, C, H, W, amount = 3, 3, 37, 41, 0.05
+    x = rng.rand(N, C, H, W).astype(np.float32)
+    n = int(np.ceil(amount * H * W * 0.5))
+    coords = [rng.randint(0, hi - 1, (N, n)).astype(np.int32) for hi in (H, W, H, W)]
+    ref = x.copy()
+    for i in range(N):
+        hwc = ref[i].transpose(1, 2, 0).copy()
+        hwc[coords[0][i], coords[1][i], :] = 1.0
+        hwc[coords[2][i], coords[3][i], :] = 0.0
+        ref[i] = hwc.transpose(2, 0, 1)
+    got = edrl.ops.salt_pepper_(torch.from_numpy(x).to(dev), amount, coords=[torch.from_numpy(c) for c in coords])
+    assert np.array_equal(got.cpu().numpy(), ref)
+    xs = torch.rand(5, 1, 16, 16, device=dev)          # device-drawn coordinates: right number of touched pixels at most
+    ys = edrl.ops.salt_pepper_(xs.clone(), 0.2)
+    changed = int((ys != xs).sum())
+    assert 0 < changed <= 5 * 2 * int(np.ceil(0.2 * 256 * 0.5))
+    assert set(ys[ys != xs].unique().tolist()) <= {0.0, 1.0}
+
+    g = torch.Generator().manual_seed(5)
+    batches = [([torch.rand(2, 3, 32, 32, generator=g), torch.rand(2, 1, 4, 32, 32, generator=g)],
+                torch.randint(0, 2, (2,), generator=g)) for _ in range(3)]
+    seen = list(edrl.DevicePrefetcher(batches, dev, sigma=0.5, drop_oct_high=True, salt_pepper=0.02))
+    assert len(seen) == 3
+    for ((low, high), y), (X, y0) in zip(seen, batches):
+        assert torch.equal(low[0].cpu(), X[0]) and torch.equal(low[1].cpu(), X[1]) and torch.equal(y.cpu(), y0)
+        assert float(high[0].min()) >= 0.0 and float(high[0].max()) <= 1.0 and float(high[1].abs().max()) == 0.0
+    args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
+    torch.manual_seed(0)
+    m = edrl.MedFusion(2, 2, None, args).to(dev)
+    opt = edrl.FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+    stats = edrl.train(0, edrl.DevicePrefetcher(batches, dev), m, opt)
+    assert stats["loss"] == stats["loss"] and 0.0 <= stats["acc"] <= 1.0
