@@ -641,7 +641,10 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
                            const float* mul, const GatherGeom& g, hipStream_t st) {
   const bool vec = (g.SC % 4 == 0) && (g.ld_src % 4 == 0) && (g.Kfull % 4 == 0) &&
                    (((uintptr_t)src & 15) == 0) && (((uintptr_t)wm & 15) == 0);
-  const bool narrow = g.NC <= 64;
+  // 64-wide N tiles for Cout <= 64 and for small grids (the head's Linear layers at 32..1568 rows leave most of the
+  // 256 CUs idle with 128-wide tiles: twice the workgroups, same work each K step)
+  static const int small_grid = []() { const char* e = getenv("EDRL_NARROW_BELOW"); return e ? atoi(e) : 512; }();
+  const bool narrow = g.NC <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(g.NC, 128) < small_grid);
   GatherGeom gv = g;
   if (vec && (g.NC % 4 == 0) && (g.ld_dst % 4 == 0) && (((uintptr_t)dst & 15) == 0) &&
       (!bias || ((uintptr_t)bias & 15) == 0) && (!mul || ((g.ld_aux % 4 == 0) && ((uintptr_t)mul & 15) == 0)))
