@@ -134,6 +134,11 @@ int edrl_maxpool3x3s2_fwd_bf16(const void* x, void* y, unsigned char* idx, int N
 int edrl_maxpool3x3s2_bwd_bf16(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
                                hipStream_t stream);
 /* 3x3 / stride 2 / pad 1 max pooling on NHWC (encoder stem); idx = window tap of the first max. */
+/* Stem re-layout (build-owned encoders): the 7x7/s2/p3 stem conv == a 4x4/s1 conv on the 2x2
+ * space-to-depth image (pads 2 top/left, 1 bottom/right).  y[n,a,b,(ph*2+pw)*C+c] = x[n,2a+ph,2b+pw,c]; H, W even. */
+int edrl_space_to_depth2_f32(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
+/* dir 0: w [Co,7,7,C] -> [Co,4,4,4C] (the unused 8th taps zero);  dir 1: the inverse gather (for the weight gradient). */
+int edrl_stem_weight_fold_f32(const float* in, float* out, int Co, int C, int dir, hipStream_t stream);
 int edrl_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C,
                               hipStream_t stream);
 int edrl_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,

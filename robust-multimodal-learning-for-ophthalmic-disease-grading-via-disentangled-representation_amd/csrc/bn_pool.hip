@@ -564,6 +564,54 @@ static inline int ew_grid(long total) {
   return (int)b;
 }
 
+// ---- stem re-layout: a 7x7 / stride-2 / pad-3 convolution over C channels equals a 4x4 / stride-1 convolution over the
+// 2x2 space-to-depth image with 4C channels (top/left pad 2, bottom/right pad 1; the 8th tap per axis has zero weight):
+//   input row i = 2*oh - 3 + kh = 2*(oh - 2 + ka) + ph   with kh + 1 = 2*ka + ph.
+// For the single-channel OCT stem this turns K = 49 scalar gathers into K = 64 with one 16-byte load per tap (the four
+// phases of a 2x2 block are the four channels), i.e. the vector MFMA path instead of the scalar fallback.
+// y[n,a,b,(ph*2+pw)*C + c] = x[n,2a+ph,2b+pw,c]
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const long total = (long)N * H2 * W2 * 4 * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ph = (int)((t >> 1) & 1), pw = (int)(t & 1);
+    t >>= 2;
+    const int b = (int)(t % W2);
+    t /= W2;
+    const int a = (int)(t % H2);
+    const int n = (int)(t / H2);
+    y[i] = x[(((long)n * H + 2 * a + ph) * W + 2 * b + pw) * C + c];
+  }
+}
+// dir 0: w7 [Co,7,7,C] -> w8 [Co,4,4,4C] (zero taps filled);  dir 1: w8 -> w7 (gather; used on the weight gradient)
+__global__ __launch_bounds__(256) void stem_weight_fold_kernel(const float* __restrict__ in, float* __restrict__ out, int Co,
+                                                               int C, int dir) {
+  const long total = dir == 0 ? (long)Co * 16 * 4 * C : (long)Co * 49 * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (dir == 0) {
+      const int c = (int)(i % C);
+      long t = i / C;
+      const int ph = (int)((t >> 1) & 1), pw = (int)(t & 1);
+      t >>= 2;
+      const int kb = (int)(t & 3), ka = (int)((t >> 2) & 3);
+      const int co = (int)(t >> 4);
+      const int kh = 2 * ka + ph - 1, kw = 2 * kb + pw - 1;
+      out[i] = (kh >= 0 && kw >= 0) ? in[(((long)co * 7 + kh) * 7 + kw) * C + c] : 0.f;
+    } else {
+      const int c = (int)(i % C);
+      long t = i / C;
+      const int kw = (int)(t % 7);
+      t /= 7;
+      const int kh = (int)(t % 7);
+      const int co = (int)(t / 7);
+      const int ka = (kh + 1) >> 1, ph = (kh + 1) & 1, kb = (kw + 1) >> 1, pw = (kw + 1) & 1;
+      out[i] = in[((((long)co * 4 + ka) * 4 + kb) * 4 + (ph * 2 + pw)) * C + c];
+    }
+  }
+}
+
 extern "C" {
 
 size_t edrl_bn_workspace_bytes(long M, int C) {
@@ -655,6 +703,18 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* re
   return 0;
 }
 
+int edrl_space_to_depth2_f32(const float* x, float* y, int N, int H, int W, int C, hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return EDRL_EINVAL;
+  hipLaunchKernelGGL(s2d_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, st, x, y, N, H, W, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_stem_weight_fold_f32(const float* in, float* out, int Co, int C, int dir, hipStream_t st) {
+  if (Co <= 0 || C <= 0 || (dir != 0 && dir != 1)) return EDRL_EINVAL;
+  hipLaunchKernelGGL(stem_weight_fold_kernel, dim3(ew_grid((long)Co * 64 * C)), dim3(256), 0, st, in, out, Co, C, dir);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
 int edrl_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C,
                               hipStream_t st) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return EDRL_EINVAL;

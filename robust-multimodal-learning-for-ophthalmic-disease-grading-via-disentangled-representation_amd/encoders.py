@@ -60,6 +60,7 @@ def _bn_fwd(raw, bn, relu, residual=None):
 
 
 _FUSE_STATS = os.environ.get("EDRL_FUSE_BN_STATS", "1") != "0"
+_STEM_S2D = os.environ.get("EDRL_STEM_S2D", "1") != "0"
 
 
 def _conv_bn_fwd(inp, w, bn, stride, pad, relu, residual=None):
@@ -116,13 +117,20 @@ class _TrunkFn(torch.autograd.Function):
         def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
             return _conv_bn_fwd(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
 
-        raw, a0, m0, r0, k0 = cb("conv1", "bn1", x, 2, 3, True)
+        # stem: as a 4x4 conv over the space-to-depth image when no input gradient is wanted (ops.stem_conv_fwd)
+        folded = False
+        if _STEM_S2D and not x.requires_grad:
+            raw, x_keep, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
+            a0, m0, r0, k0 = _bn_fwd(raw, bnd("bn1", p), True)
+        else:
+            raw, a0, m0, r0, k0 = cb("conv1", "bn1", x, 2, 3, True)
+            x_keep = x
         N, H, W, C = a0.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         p0 = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
         idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
         L.call("edrl_maxpool3x3s2_fwd_f32", P(a0), P(p0), P(idx), N, H, W, C)
-        saved["stem"] = (x, raw, a0.shape, m0, r0, k0, idx)
+        saved["stem"] = (x_keep, folded, raw, a0.shape, m0, r0, k0, idx)
         cur = p0
         for blk in T.blocks:
             pre, s = blk["name"], blk["stride"]
@@ -216,12 +224,16 @@ class _TrunkFn(torch.autograd.Function):
             del g
             dcur = dx
             del rec
-        x, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
+        x, folded, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
         N, H, W, C = a0_shape
         da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.float32)
         L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
         draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))
-        dx = conv_bwd("conv1", draw, x, 2, 3, need_dx=ctx.needs_x)
+        if folded:
+            grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), True)
+            dx = None
+        else:
+            dx = conv_bwd("conv1", draw, x, 2, 3, need_dx=ctx.needs_x)
         if side is not None:
             main.wait_stream(side)
         return (None, dx) + tuple(grads.get(n) for n in T.param_names)
@@ -281,7 +293,10 @@ class _TrunkBf16Fn(torch.autograd.Function):
             return _conv_bn_fwd_bf16(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
 
         # stem: fp32 conv + fp32 statistics, bf16 activation out
-        raw = ops.conv2d_fwd(x, p["conv1.weight"], stride=2, pad=3)
+        if _STEM_S2D:
+            raw, x, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
+        else:
+            raw, folded = ops.conv2d_fwd(x, p["conv1.weight"], stride=2, pad=3), False
         bn = bnd("bn1", p)
         C = raw.shape[-1]
         M = raw.numel() // C
@@ -299,7 +314,7 @@ class _TrunkBf16Fn(torch.autograd.Function):
         p0 = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.bfloat16)
         idx = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.uint8)
         L.call("edrl_maxpool3x3s2_fwd_bf16", P(a0), P(p0), P(idx), N, H, W, C)
-        saved["stem"] = (x, raw, a0.shape, m0, r0, k0, idx)
+        saved["stem"] = (x, folded, raw, a0.shape, m0, r0, k0, idx)
         cur = p0
         for blk in T.blocks:
             pre, s = blk["name"], blk["stride"]
@@ -370,13 +385,13 @@ class _TrunkBf16Fn(torch.autograd.Function):
                 conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad, dx_out=dx, accumulate=True)
             dcur = dx
             del rec, g
-        x, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
+        x, folded, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
         N, H, W, C = a0_shape
         da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.bfloat16)
         L.call("edrl_maxpool3x3s2_bwd_bf16", P(dcur), P(idx), P(da0), N, H, W, C)
         draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))            # raw is fp32 -> fp32 gradient for the fp32 stem wgrad
         w1 = p["conv1.weight"]
-        grads["conv1.weight"] = ops.conv2d_wgrad(draw, x, tuple(w1.shape), 2, 3)
+        grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(w1.shape), folded)
         return (None, None) + tuple(grads.get(n) for n in T.param_names)
 
 

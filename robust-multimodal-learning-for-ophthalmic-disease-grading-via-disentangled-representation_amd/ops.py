@@ -90,16 +90,20 @@ def ew(op, a, b=None, c=None, out=None, alpha=1.0, beta=1.0):
     return out
 
 
-def conv2d_fwd(x, w, bias=None, mul=None, stride=1, pad=0, relu=False, out=None, accumulate=False):
-    """x [N,Hi,Wi,Ci] NHWC, w [Co,KH,KW,Ci] -> y [N,Ho,Wo,Co]."""
+def conv2d_fwd(x, w, bias=None, mul=None, stride=1, pad=0, relu=False, out=None, accumulate=False, out_hw=None,
+               alg_flops=None):
+    """x [N,Hi,Wi,Ci] NHWC, w [Co,KH,KW,Ci] -> y [N,Ho,Wo,Co].  out_hw overrides (Ho, Wo) (asymmetric padding: taps
+    beyond the bottom/right edge read zeros); alg_flops overrides the algorithmic FLOP count given to the kernel timer."""
     N, Hi, Wi, Ci = x.shape
     Co, KH, KW, _ = w.shape
     Ho = (Hi + 2 * pad - KH) // stride + 1
     Wo = (Wi + 2 * pad - KW) // stride + 1
+    if out_hw is not None:
+        Ho, Wo = out_hw
     if out is None:
         out = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.float32)
     flags = (FLAG_RELU if relu else 0) | (FLAG_ACCUM if accumulate else 0)
-    _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_f32", P(x), P(w), P(bias),
+    _launch_timed("conv_gather", alg_flops or 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_f32", P(x), P(w), P(bias),
                   P(mul), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Ci, Co, Co, flags)
     return out
 
@@ -117,6 +121,49 @@ def conv2d_fwd_stats(x, w, stat_shift, stride=1, pad=0):
     _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_stats_f32", P(x), P(w), P(out),
                   P(stat_shift), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)
     return out, part, chunks
+
+
+def space_to_depth2(x):
+    """[N,H,W,C] -> [N,H/2,W/2,4C], channel order (ph, pw, c)."""
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, 4 * C), device=x.device, dtype=torch.float32)
+    L.call("edrl_space_to_depth2_f32", P(x), P(y), N, H, W, C)
+    return y
+
+
+def stem_weight_fold(w, inverse=False):
+    """7x7 stem weight [Co,7,7,C] <-> its 4x4 space-to-depth form [Co,4,4,4C] (inverse: gather back, for gradients)."""
+    Co = w.shape[0]
+    if inverse:
+        C = w.shape[3] // 4
+        out = torch.empty((Co, 7, 7, C), device=w.device, dtype=torch.float32)
+    else:
+        C = w.shape[3]
+        out = torch.empty((Co, 4, 4, 4 * C), device=w.device, dtype=torch.float32)
+    L.call("edrl_stem_weight_fold_f32", P(w.contiguous()), P(out), Co, C, 1 if inverse else 0)
+    return out
+
+
+def stem_conv_fwd(x, w):
+    """The 7x7/s2/p3 stem conv.  Even H, W: 4x4/s1 conv on the space-to-depth image (vector MFMA path, K = 64*C/…);
+    -> (y [N,H/2,W/2,Co], the tensor to keep for the weight gradient, folded flag)."""
+    N, H, W, C = x.shape
+    Co = w.shape[0]
+    if (H % 2 == 0) and (W % 2 == 0) and tuple(w.shape[1:3]) == (7, 7):
+        xs = space_to_depth2(x)
+        y = conv2d_fwd(xs, stem_weight_fold(w), stride=1, pad=2, out_hw=(H // 2, W // 2),
+                       alg_flops=2.0 * N * (H // 2) * (W // 2) * Co * 49 * C)
+        return y, xs, True
+    return conv2d_fwd(x, w, stride=2, pad=3), x, False
+
+
+def stem_conv_wgrad(dy, x_saved, w_shape, folded):
+    if not folded:
+        return conv2d_wgrad(dy, x_saved, tuple(w_shape), 2, 3)
+    Co, _, _, C = w_shape
+    N, Ho, Wo, _ = dy.shape
+    dw8 = conv2d_wgrad(dy, x_saved, (Co, 4, 4, 4 * C), 1, 2, alg_flops=2.0 * N * Ho * Wo * Co * 49 * C)
+    return stem_weight_fold(dw8, inverse=True)
 
 
 def permute_weight(w):
@@ -143,7 +190,7 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=False):
     return out
 
 
-def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False):
+def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False, alg_flops=None):
     N, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
     KH, KW = w_shape[1], w_shape[2]
@@ -152,7 +199,7 @@ def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False):
         accumulate = False
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
     ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
-    _launch_timed("conv_wgrad", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_f32", P(dy), P(x),
+    _launch_timed("conv_wgrad", alg_flops or 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_f32", P(dy), P(x),
                   P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, 1 if accumulate else 0)
     return out
 

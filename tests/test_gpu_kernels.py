@@ -413,3 +413,27 @@ def test_fused_adam_vs_torch_adam(edrl, dev):
     oc = torch.optim.Adam(pb, lr=1e-2, weight_decay=1e-6)
     oc.load_state_dict(oa.state_dict())           # checkpoint interchange with the stock optimiser
     assert float(oc.state[pb[0]]["step"]) == 5.0
+
+
+@pytest.mark.parametrize("C,N,H,W", [(1, 3, 30, 34), (4, 2, 32, 32)])
+def test_stem_space_to_depth_conv_equals_7x7_conv(edrl, dev, C, N, H, W):
+    """ops.stem_conv_fwd / stem_conv_wgrad (4x4 conv on the 2x2 space-to-depth image, folded weights) against fp64
+    F.conv2d(k=7, s=2, p=3) and its weight gradient: same tolerance as the direct MFMA contractions (2e-5)."""
+    ops = edrl.ops
+    torch.manual_seed(4)
+    x = torch.randn(N, C, H, W)
+    w = torch.randn(64, C, 7, 7) * 0.1
+    xd = x.double().requires_grad_(False)
+    wd = w.double().requires_grad_(True)
+    y_ref = torch.nn.functional.conv2d(xd, wd, stride=2, padding=3)
+    gy = torch.randn(y_ref.shape)
+    y_ref.backward(gy.double())
+    xh = nhwc(x).to(dev)
+    wh = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    y, keep, folded = ops.stem_conv_fwd(xh, wh)
+    assert folded and keep.shape == (N, H // 2, W // 2, 4 * C)
+    check(f"stem_s2d_fwd[C={C}]", y.cpu().permute(0, 3, 1, 2), y_ref.detach(), 2e-5)
+    dw = ops.stem_conv_wgrad(nhwc(gy).to(dev), keep, tuple(wh.shape), folded)
+    check(f"stem_s2d_wgrad[C={C}]", dw.cpu().permute(0, 3, 1, 2), wd.grad, 2e-5)
+    w8 = ops.stem_weight_fold(wh)
+    assert torch.equal(ops.stem_weight_fold(w8, inverse=True), wh)      # fold / unfold are exact copies
