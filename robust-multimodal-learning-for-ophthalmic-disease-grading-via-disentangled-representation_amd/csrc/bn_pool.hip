@@ -612,6 +612,161 @@ __global__ __launch_bounds__(256) void stem_weight_fold_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 / bf16 specialisations, 8 channels (one 16-byte access) per lane: the templated kernels above move 8 bytes per
+// lane on bf16 tensors, which leaves HBM bandwidth on the table (measured 4.1 vs 5.0 TB/s).  C % 8 == 0.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void ld8h(const __bf16* p, float* o) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+__device__ __forceinline__ void st8h(__bf16* p, const float* o) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (__bf16)o[e];
+  *reinterpret_cast<bf16x8*>(p) = v;
+}
+__device__ __forceinline__ void ld8f(const float* p, float* o) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_h8_kernel(const __bf16* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const __bf16* __restrict__ residual, __bf16* __restrict__ out,
+                                                          unsigned char* __restrict__ mask_out, long M, int C, int relu) {
+  const int C8 = C >> 3;
+  const long total = M * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C8;
+    const int c = (int)(i - r * C8) * 8;
+    float xv[8], mu[8], sc[8], sf[8], v[8];
+    ld8h(x + r * C + c, xv);
+    ld8f(mean + c, mu); ld8f(scale + c, sc); ld8f(shift + c, sf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (xv[e] - mu[e]) * sc[e] + sf[e];
+    if (residual) {
+      float rv[8];
+      ld8h(residual + r * C + c, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    if (relu) {
+      if (mask_out) {   // same layout as the 4-wide kernels: one byte (4 sign bits) per 4 channels -> two bytes here
+        int mb = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mb |= (v[e] > 0.f ? 1 : 0) << (e < 4 ? e : e + 4);
+        *reinterpret_cast<unsigned short*>(mask_out + i * 2) = (unsigned short)mb;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    st8h(out + r * C + c, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const __bf16* __restrict__ dout,
+                                                              const unsigned char* __restrict__ rmask,
+                                                              const __bf16* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ coef, __bf16* __restrict__ dx,
+                                                              __bf16* __restrict__ dres, long M, int C) {
+  const int C8 = C >> 3;
+  const long total = M * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C8;
+    const int c = (int)(i - r * C8) * 8;
+    float g[8], xv[8], mu[8], rs[8], c1[8], c2[8], gm[8], d[8];
+    ld8h(dout + r * C + c, g);
+    ld8h(x + r * C + c, xv);
+    if (rmask) {
+      const int mb = *reinterpret_cast<const unsigned short*>(rmask + i * 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = (mb >> (e < 4 ? e : e + 4)) & 1 ? g[e] : 0.f;
+    }
+    ld8f(mean + c, mu); ld8f(rstd + c, rs); ld8f(coef + c, c1); ld8f(coef + C + c, c2);
+    if (gamma) ld8f(gamma + c, gm);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (xv[e] - mu[e]) * rs[e];
+      d[e] = (gamma ? gm[e] : 1.f) * rs[e] * (g[e] - c1[e] - xh * c2[e]);
+    }
+    if (dres) st8h(dres + r * C + c, g);
+    st8h(dx + r * C + c, d);
+  }
+}
+
+// (sum g, sum g*xhat) partials, g = dout * relu-mask: part[chunk][3][C] like colstat_kernel<1>
+__global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dout,
+                                                          const unsigned char* __restrict__ rmask,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          long M, int C, float* __restrict__ part) {
+  __shared__ float sh[256 * 16];
+  const int C8 = C >> 3;
+  const int CG = C8 < 64 ? C8 : 64;      // 8-channel groups per block (C8 is a power of two or the block tail is idle)
+  const int RL = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, rl = tid / CG;
+  const int c = (blockIdx.y * 64 + cg) * 8;
+  const long row0 = (long)blockIdx.x * BN_ROWS_PER_CHUNK;
+  long row1 = row0 + BN_ROWS_PER_CHUNK;
+  if (row1 > M) row1 = M;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  if (c < C && rl < RL) {
+    float mu[8], rs[8];
+    ld8f(mean + c, mu); ld8f(rstd + c, rs);
+    constexpr int U = 2;
+    long r = row0 + rl;
+    auto acc = [&](const float* xv, float* g, int mb, bool masked) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ge = (!masked || ((mb >> (e < 4 ? e : e + 4)) & 1)) ? g[e] : 0.f;
+        s0[e] += ge;
+        s1[e] += ge * ((xv[e] - mu[e]) * rs[e]);
+      }
+    };
+    for (; r + (long)(U - 1) * RL < row1; r += (long)U * RL) {
+      float xv[U][8], gv[U][8];
+      int mb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long rr = r + (long)u * RL;
+        ld8h(x + rr * C + c, xv[u]);
+        ld8h(dout + rr * C + c, gv[u]);
+        mb[u] = rmask ? *reinterpret_cast<const unsigned short*>(rmask + (rr * C8 + (c >> 3)) * 2) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc(xv[u], gv[u], mb[u], rmask != nullptr);
+    }
+    for (; r < row1; r += RL) {
+      float xv[8], gv[8];
+      ld8h(x + r * C + c, xv);
+      ld8h(dout + r * C + c, gv);
+      const int mb = rmask ? *reinterpret_cast<const unsigned short*>(rmask + (r * C8 + (c >> 3)) * 2) : 0;
+      acc(xv, gv, mb, rmask != nullptr);
+    }
+  }
+  float* my = sh + tid * 16;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { my[e] = s0[e]; my[8 + e] = s1[e]; }
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float a[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+    for (int q = 0; q < RL; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a[e] += sh[(q * CG + cg) * 16 + e];
+    float* p = part + (long)blockIdx.x * 3 * C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { p[c + e] = a[e]; p[C + c + e] = a[8 + e]; }
+  }
+}
+
 extern "C" {
 
 size_t edrl_bn_workspace_bytes(long M, int C) {
@@ -774,7 +929,10 @@ int edrl_bn_apply_mx(const void* x, int raw_bf16, const float* mean, const float
                      hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
   const dim3 grid(ew_grid(M * (C / 4)));
-  if (raw_bf16 && act_bf16)
+  if (raw_bf16 && act_bf16 && (C & 7) == 0)
+    hipLaunchKernelGGL(bn_apply_h8_kernel, dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)x, mean, scale, shift,
+                       (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, relu);
+  else if (raw_bf16 && act_bf16)
     hipLaunchKernelGGL((bn_apply_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)x, mean, scale, shift,
                        (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, (long)C, relu);
   else if (!raw_bf16 && act_bf16)
@@ -809,6 +967,23 @@ static int bn_bwd_mx_impl(const TA* dout, const unsigned char* relu_mask, const 
   EDRL_LAUNCH_CHECK();
   return 0;
 }
+static int bn_bwd_h8_impl(const __bf16* dout, const unsigned char* relu_mask, const __bf16* x, const float* save_mean,
+                          const float* save_rstd, const float* gamma, float* dgamma, float* dbeta, __bf16* dx, __bf16* dres,
+                          long M, int C, float* workspace, hipStream_t st) {
+  const size_t stats = edrl_bn_workspace_bytes(M, C);
+  float* coef = workspace + stats / sizeof(float);
+  const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL(colstat1_h8_kernel, dim3(chunks, edrl_cdiv(C, 512)), dim3(256), 0, st, x, dout, relu_mask, save_mean,
+                     save_rstd, M, C, workspace);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M, dgamma,
+                     dbeta, 0, coef);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_apply_h8_kernel, dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, dout, relu_mask, x, save_mean,
+                     save_rstd, gamma, coef, dx, dres, M, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" {
 
 int edrl_bn_bwd_mx(const void* dout, int act_bf16, const unsigned char* relu_mask, const void* x, int raw_bf16,
@@ -816,6 +991,9 @@ int edrl_bn_bwd_mx(const void* dout, int act_bf16, const unsigned char* relu_mas
                    void* dres, long M, int C, float* workspace, size_t workspace_bytes, hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
   if (workspace_bytes < edrl_bn_workspace_bytes(M, C) + (size_t)2 * C * sizeof(float)) return EDRL_ENOSPC;
+  if (raw_bf16 && act_bf16 && (C & 7) == 0)
+    return bn_bwd_h8_impl((const __bf16*)dout, relu_mask, (const __bf16*)x, save_mean, save_rstd, gamma, dgamma, dbeta,
+                          (__bf16*)dx, (__bf16*)dres, M, C, workspace, st);
   if (raw_bf16 && act_bf16)
     return bn_bwd_mx_impl<__bf16, __bf16>((const __bf16*)dout, relu_mask, (const __bf16*)x, save_mean, save_rstd, gamma,
                                           dgamma, dbeta, (__bf16*)dx, (__bf16*)dres, M, C, workspace, st);
