@@ -33,7 +33,7 @@ _CFG = {
 # EDRL_WGRAD_STREAM=1 issues the weight-gradient kernels on a side stream (measured +2 % images/s at C1: they overlap
 # the HBM-bound BatchNorm-backward kernels).  Off by default: concurrent streams inflate every per-kernel duration
 # (HIP events and rocprof alike), which would blur the roofline measurement of the dominant kernel.
-_WGRAD_SIDE_STREAM = os.environ.get("EDRL_WGRAD_STREAM", "0") == "1"
+_WGRAD_SIDE_STREAM = os.environ.get("EDRL_WGRAD_STREAM", "0") == "1"   # wgrad beside the next BatchNorm backward
 
 
 def _bn_ws(M, C, device, extra=0):
@@ -175,16 +175,24 @@ class _TrunkFn(torch.autograd.Function):
             w = p[name + ".weight"]
             if side is None:
                 grads[name + ".weight"] = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
-            else:
-                side.wait_event(main.record_event())
-                with torch.cuda.stream(side):
-                    dw = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
-                dy.record_stream(side); inp.record_stream(side); dw.record_stream(main)
-                grads[name + ".weight"] = dw
-            if not need_dx:
-                return None
-            return ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
-                                    accumulate=accumulate)
+                if not need_dx:
+                    return None
+                return ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
+                                        accumulate=accumulate)
+            # Side-stream schedule: [join the previous wgrad] -> dgrad (alone on the GPU: its timing stays clean) ->
+            # wgrad on the side stream, which then runs beside the NEXT layer's BatchNorm-backward kernels (MFMA-bound
+            # beside HBM-bound) until the next dgrad joins it.
+            main.wait_stream(side)
+            dx = None
+            if need_dx:
+                dx = ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
+                                      accumulate=accumulate)
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                dw = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+            dy.record_stream(side); inp.record_stream(side); dw.record_stream(main)
+            grads[name + ".weight"] = dw
+            return dx
 
         def bn_bwd(name, dy, mask, raw, st, want_dres=False):
             d_raw, dg, db, dres = _bn_bwd(dy, mask, raw, st[0], st[1], p[name + ".weight"], want_dres)
