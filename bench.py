@@ -29,6 +29,8 @@ CONFIGS = {
     "C2": (64, 50, 224, 32, "bf16", "C2: B=64/GPU, ResNet-50 encoders on the bf16 MFMA path, 224x224 fundus + 32-slice OCT"),
     # BASELINE.json configs[4] per-GPU shape (an 8-GPU config; B=3 is the largest per-GPU batch whose saved activations
     # fit 288 GB): 512x512 fundus + 128-slice OCT, second view with the OCT volume dropped (zeros), bf16 encoders.
+    # C1 shapes with the true 3-D-conv OCT encoder (ResNet3D-18 over the 32x224x224 volume)
+    "C1-3D": (32, 50, 224, 32, "fp32", "C1-3D: B=32/GPU, ResNet-50 fundus encoder + ResNet3D-18 OCT volume encoder, 224x224 fundus + 32-slice OCT, fp32"),
     "C4": (3, 50, 512, 128, "bf16", "C4: B=3/GPU, ResNet-50 bf16 encoders, 512x512 fundus + 128-slice OCT, OCT-dropped second view"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
@@ -75,7 +77,7 @@ def main():
         B = a.batch
         desc = desc.replace(f"B={CONFIGS[a.config][0]}/GPU", f"B={B}/GPU (override)")
     args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, strict_labels=False,
-                                 encoder_dtype=enc_dtype)
+                                 encoder_dtype=enc_dtype, oct_encoder="3d" if a.config == "C1-3D" else "slices", oct3d_depth=18)
     torch.manual_seed(0)
     model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
     edrl_amd.broadcast_parameters(model)

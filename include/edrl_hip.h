@@ -269,6 +269,19 @@ int edrl_mk_mmd_fwd_f32(const float* G, const float* sq, int n, int ns, float ke
 int edrl_mk_mmd_bwd_f32(const float* dloss, const float* G, const float* sq, const float* saved, int n, int ns,
                         float kernel_mul, int kernel_num, float* workspace, float* coef, hipStream_t stream);
 
+/* ---- volume operators (vol_ops.hip): the 3-D-conv OCT encoder alternative of SURVEY.md §8(f) row 4 (build-owned; the
+ * reference's 3-D encoder source is absent, call site fusion_net.py:799,885; shapes after baseline_models.py:154-178) ----
+ * Depth unfold: y[n,do,p,kd*C+c] = x[n, do*sd - pd + kd, p, c] (0 outside; channels >= KD*C are zero padding up to CK), so a
+ * KD x k x k conv is the 2-D conv of edrl_conv2d_nhwc_* over N*Do slices with CK channels; depth fold is its adjoint. */
+int edrl_depth_unfold_f32(const float* x, float* y, int N, int D, long P, int C, int KD, int sd, int pd, int Do, int CK,
+                          hipStream_t stream);
+int edrl_depth_fold_f32(const float* dy, float* dx, int N, int D, long P, int C, int KD, int sd, int pd, int Do, int CK,
+                        hipStream_t stream);
+/* Depth half of MaxPool3d(3, stride 2, pad 1) on [N,D,PC] (PC = H*W*C); idx = winning tap 0..2. */
+int edrl_maxpool_depth3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int D, long PC, hipStream_t stream);
+int edrl_maxpool_depth3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int N, int D, long PC,
+                                  hipStream_t stream);
+
 /* ---- optimiser (optim.hip) -------------------------------------------------------------------------------------
  * Fused multi-tensor Adam: replaces `optimizer.step()` of torch.optim.Adam(model.parameters(), lr, weight_decay=1e-6)
  * (fusion_train.py:224, :747).  tensors: device array of {float* p; const float* g; float* m;

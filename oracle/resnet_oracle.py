@@ -119,3 +119,46 @@ def trunk_state(trunk, dtype=torch.float64, requires_grad=True):
         n = n.replace("__", ".")
         sd[n] = b.detach().cpu().to(dtype) if b.dtype.is_floating_point else b.detach().cpu().clone()
     return sd
+
+
+# ---------------------------------------------------------------------------------------------- 3-D-conv OCT trunk
+def _w3d(w, k, ci):
+    """product layout [Co,KH,KW,CK] (CK = KD*Ci padded) -> torch [Co,Ci,KD,KH,KW]"""
+    co = w.shape[0]
+    return w[..., : k * ci].reshape(co, k, k, k, ci).permute(0, 4, 3, 1, 2)
+
+
+def trunk3d_forward(x, sd, n_blocks_per_layer):
+    """Oracle of encoders3d.ResNet3DTrunk (parity unpinned by the reference: no source): torch-CPU
+    F.conv3d / F.batch_norm(training=True) / F.relu / F.max_pool3d in the MedicalNet-style basic-block topology.
+    x [N,1,D,H,W]; sd: name -> tensor from trunk3d_state(); -> [N,512,d,h,w]."""
+    def conv(x, name, k, stride, pad):
+        return F.conv3d(x, _w3d(sd[name + ".weight"], k, x.shape[1]), stride=stride, padding=pad)
+
+    def bn(x, name):
+        return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
+                            sd[name + ".bias"], True, 0.1, 1e-5)
+
+    x = F.max_pool3d(F.relu(bn(conv(x, "conv1", 7, 2, 3), "bn1")), 3, 2, 1)
+    bi, ci = 0, 64
+    for li, (co, n) in enumerate(zip([64, 128, 256, 512], n_blocks_per_layer)):
+        for b in range(n):
+            stride = 2 if (b == 0 and li > 0) else 1
+            pre = f"blocks.{bi}"
+            idn = x
+            if stride != 1 or ci != co:
+                idn = bn(conv(x, pre + ".down.0", 1, stride, 0), pre + ".down.1")
+            o = F.relu(bn(conv(x, pre + ".conv1", 3, stride, 1), pre + ".bn1"))
+            x = F.relu(bn(conv(o, pre + ".conv2", 3, 1, 1), pre + ".bn2") + idn)
+            bi += 1
+            ci = co
+    return x
+
+
+def trunk3d_state(trunk, dtype=torch.float64, requires_grad=True):
+    sd = {}
+    for n, p in trunk.named_parameters():
+        sd[n] = p.detach().cpu().to(dtype).requires_grad_(requires_grad)
+    for n, b in trunk.named_buffers():
+        sd[n] = b.detach().cpu().to(dtype) if b.dtype.is_floating_point else b.detach().cpu().clone()
+    return sd

@@ -1,0 +1,206 @@
+"""3-D-conv OCT encoder: the "true 3D" alternative for the `transformer_3DNet` slot
+(fusion_net.py:799,885; the reference's own 3-D networks are MedicalNet ResNets, baseline_models.py:123-178, whose source
+is absent).  Build-owned ResNet3D-10/18 (basic blocks, 7x7x7/s2 stem, MaxPool3d(3,2,1), stride-2 stages with 1x1x1
+"type B" shortcuts), NDHWC fp32, behind the same `(tokens, pooled)` contract as the slice-stack encoder.
+
+Every 3-D convolution runs as a 2-D implicit-GEMM convolution over the depth-unfolded volume (csrc/vol_ops.hip):
+weights are stored [Co, KH, KW, KD*Ci] (K order of the 2-D MFMA kernel), BatchNorm3d is the 2-D BatchNorm kernels over
+N*D*H*W rows, MaxPool3d is the 2-D max-pool per slice followed by a depth max.  Parity is unpinned by the reference
+(no source); the oracle is torch-CPU F.conv3d / F.batch_norm / F.max_pool3d (oracle/resnet_oracle.py).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .encoders import _bn_fwd, _bn_bwd
+
+P = L.ptr
+
+
+def depth_unfold(x5, KD, sd, pd, CK):
+    N, D, H, W, C = x5.shape
+    Do = (D + 2 * pd - KD) // sd + 1
+    y = torch.empty((N, Do, H, W, CK), device=x5.device, dtype=torch.float32)
+    L.call("edrl_depth_unfold_f32", P(x5), P(y), N, D, H * W, C, KD, sd, pd, Do, CK)
+    return y
+
+
+def depth_fold(dy5, x_shape, KD, sd, pd):
+    N, D, H, W, C = x_shape
+    Do, CK = dy5.shape[1], dy5.shape[4]
+    dx = torch.empty(x_shape, device=dy5.device, dtype=torch.float32)
+    L.call("edrl_depth_fold_f32", P(dy5), P(dx), N, D, H * W, C, KD, sd, pd, Do, CK)
+    return dx
+
+
+class Conv3dFn(torch.autograd.Function):
+    """x [N,D,H,W,C], w [Co,KH,KW,CK] (CK = KD*C padded to a multiple of 4) -> y [N,Do,Ho,Wo,Co]; no bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, KD, sd, s, pd, p):
+        x = ops._chk(x, "conv3d.x").contiguous()
+        N, D, H, W, C = x.shape
+        Co, KH, KW, CK = w.shape
+        xu = depth_unfold(x, KD, sd, pd, CK)
+        Do = xu.shape[1]
+        y = ops.conv2d_fwd(xu.view(N * Do, H, W, CK), w, stride=s, pad=p,
+                           alg_flops=2.0 * N * Do * ((H + 2 * p - KH) // s + 1) * ((W + 2 * p - KW) // s + 1) * Co * KH * KW * KD * C)
+        ctx.save_for_backward(xu, w)
+        ctx.cfg = (tuple(x.shape), KD, sd, s, pd, p)
+        return y.view(N, Do, y.shape[1], y.shape[2], Co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xu, w = ctx.saved_tensors
+        x_shape, KD, sd, s, pd, p = ctx.cfg
+        N, Do, H, W, CK = xu.shape
+        dy4 = dy.contiguous().view(N * Do, dy.shape[2], dy.shape[3], dy.shape[4])
+        xu4 = xu.view(N * Do, H, W, CK)
+        dw = ops.conv2d_wgrad(dy4, xu4, tuple(w.shape), s, p) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxu = ops.conv2d_dgrad(dy4, ops.permute_weight(w), tuple(xu4.shape), s, p)
+            dx = depth_fold(dxu.view(N, Do, H, W, CK), x_shape, KD, sd, pd)
+        return dx, dw, None, None, None, None, None
+
+
+class BnActFn(torch.autograd.Function):
+    """Train-mode BatchNorm over all leading dims (+ residual) (+ ReLU) with the 2-D BatchNorm kernels; running
+    statistics updated in place (momentum 0.1, eps 1e-5)."""
+
+    @staticmethod
+    def forward(ctx, raw, weight, bias, running_mean, running_var, relu, residual):
+        raw = raw.contiguous()
+        bn = {"weight": weight, "bias": bias, "running_mean": running_mean, "running_var": running_var,
+              "momentum": 0.1, "eps": 1e-5}
+        res = None if residual is None else residual.contiguous()
+        out, mean, rstd, mask = _bn_fwd(raw, bn, relu, res)
+        ctx.save_for_backward(raw, mean, rstd, weight, mask if mask is not None else torch.empty(0, device=raw.device))
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        raw, mean, rstd, weight, mask = ctx.saved_tensors
+        d_raw, dg, db, dres = _bn_bwd(dout.contiguous(), mask if ctx.relu else None, raw, mean, rstd, weight, ctx.has_res)
+        return d_raw, dg, db, None, None, None, dres
+
+
+class MaxPool3dFn(torch.autograd.Function):
+    """MaxPool3d(kernel 3, stride 2, pad 1) on [N,D,H,W,C]: 2-D max-pool per slice, then the depth max."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        N, D, H, W, C = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        Do = (D + 2 - 3) // 2 + 1
+        y2 = torch.empty((N, D, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        i2 = torch.empty((N, D, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        L.call("edrl_maxpool3x3s2_fwd_f32", P(x), P(y2), P(i2), N * D, H, W, C)
+        y = torch.empty((N, Do, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        i1 = torch.empty((N, Do, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        L.call("edrl_maxpool_depth3s2_fwd_f32", P(y2), P(y), P(i1), N, D, Ho * Wo * C)
+        ctx.save_for_backward(i2, i1)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        i2, i1 = ctx.saved_tensors
+        N, D, H, W, C = ctx.shape
+        Ho, Wo = i2.shape[2], i2.shape[3]
+        d2 = torch.empty((N, D, Ho, Wo, C), device=dy.device, dtype=torch.float32)
+        L.call("edrl_maxpool_depth3s2_bwd_f32", P(dy.contiguous()), P(i1), P(d2), N, D, Ho * Wo * C)
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        L.call("edrl_maxpool3x3s2_bwd_f32", P(d2), P(i2), P(dx), N * D, H, W, C)
+        return dx
+
+
+_CFG3D = {10: [1, 1, 1, 1], 18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+
+
+class _Conv3d(nn.Module):
+    def __init__(self, ci, co, k, stride, pad):
+        super().__init__()
+        self.k, self.stride, self.pad, self.ci = k, stride, pad, ci
+        ck = (k * ci + 3) // 4 * 4
+        w = torch.empty(co, k, k, ck).normal_(0.0, (2.0 / (co * k ** 3)) ** 0.5)    # Kaiming normal, fan_out, ReLU
+        w[..., k * ci:] = 0.0                       # padded K columns: zero, and their gradient is exactly zero
+        self.weight = nn.Parameter(w)
+
+    def forward(self, x):
+        return Conv3dFn.apply(x, self.weight, self.k, self.stride, self.stride, self.pad, self.pad)
+
+
+class _Bn3d(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
+
+    def forward(self, raw, relu, residual=None):
+        if not self.training:
+            raise RuntimeError("ResNet3DTrunk: eval-mode BatchNorm3d is not built (training path only)")
+        self.num_batches_tracked += 1
+        return BnActFn.apply(raw, self.weight, self.bias, self.running_mean, self.running_var, relu, residual)
+
+
+class _BasicBlock3d(nn.Module):
+    def __init__(self, ci, co, stride):
+        super().__init__()
+        self.conv1, self.bn1 = _Conv3d(ci, co, 3, stride, 1), _Bn3d(co)
+        self.conv2, self.bn2 = _Conv3d(co, co, 3, 1, 1), _Bn3d(co)
+        self.down = None
+        if stride != 1 or ci != co:
+            self.down = nn.ModuleList([_Conv3d(ci, co, 1, stride, 0), _Bn3d(co)])
+
+    def forward(self, x):
+        idn = x if self.down is None else self.down[1](self.down[0](x), False)
+        o = self.bn1(self.conv1(x), True)
+        return self.bn2(self.conv2(o), True, idn)
+
+
+class ResNet3DTrunk(nn.Module):
+    """[N,D,H,W,1] -> [N,d,h,w,512] (d = D/16, h = H/32, w = W/32 for sizes divisible by 32)."""
+
+    def __init__(self, depth=18, in_ch=1):
+        super().__init__()
+        layers = _CFG3D[depth]
+        self.depth = depth
+        self.conv1, self.bn1 = _Conv3d(in_ch, 64, 7, 2, 3), _Bn3d(64)
+        blocks, ci = [], 64
+        for li, (co, n) in enumerate(zip([64, 128, 256, 512], layers)):
+            for bi in range(n):
+                blocks.append(_BasicBlock3d(ci, co, 2 if (bi == 0 and li > 0) else 1))
+                ci = co
+        self.blocks = nn.ModuleList(blocks)
+        self.out_channels = 512
+
+    def forward(self, x):
+        x = MaxPool3dFn.apply(self.bn1(self.conv1(x), True))
+        for b in self.blocks:
+            x = b(x)
+        return x
+
+
+class OCTVolumeEncoder(nn.Module):
+    """3-D-conv OCT encoder slot: [B,1,S,H,W] -> (tokens [B, d*h*w, token_dim], pooled [B, token_dim])."""
+
+    def __init__(self, depth=18, token_dim=768):
+        super().__init__()
+        self.trunk = ResNet3DTrunk(depth, in_ch=1)
+        self.token_proj = nn.Linear(self.trunk.out_channels, token_dim)
+
+    def forward(self, x):
+        ops._chk(x, "oct")
+        B, C, S, H, W = x.shape
+        assert C == 1
+        f = self.trunk(x.view(B, S, H, W, 1))                       # single channel: NCDHW == NDHWC
+        tokens = ops.linear(f.view(B, f.shape[1] * f.shape[2] * f.shape[3], f.shape[4]), self.token_proj.weight,
+                            self.token_proj.bias)
+        return tokens, ops.mean_axis1(tokens)

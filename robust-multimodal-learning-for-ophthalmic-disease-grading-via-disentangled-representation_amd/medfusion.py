@@ -271,7 +271,11 @@ class MedFusion(nn.Module):
         depth = getattr(args, "encoder_depth", 50)
         enc_dtype = getattr(args, "encoder_dtype", "fp32")      # "bf16": bf16 MFMA encoders (C2/C4), fp32 head
         self.transformer_2DNet = FundusEncoder(depth, self.fundus_embedding_dim, enc_dtype)
-        self.transformer_3DNet = OCTSliceEncoder(depth, self.oct_embedding_dim, enc_dtype)
+        if getattr(args, "oct_encoder", "slices") == "3d":     # true 3-D-conv alternative, fp32
+            from .encoders3d import OCTVolumeEncoder
+            self.transformer_3DNet = OCTVolumeEncoder(getattr(args, "oct3d_depth", 18), self.oct_embedding_dim)
+        else:
+            self.transformer_3DNet = OCTSliceEncoder(depth, self.oct_embedding_dim, enc_dtype)
         self.fc_fundus = nn.Sequential(nn.ReLU(), nn.Linear(512, 1024), nn.ReLU())
         self.fc = nn.Sequential(nn.ReLU(), nn.Linear(3072, 64), nn.ReLU(), nn.Linear(64, self.classes))
         self.EPRL_fundus = EPRL(self.fundus_embedding_dim, num_classes=self.num_classes, topk=self.topk_fundus,
@@ -348,7 +352,8 @@ class MedFusion(nn.Module):
         return pred, loss, combine_features
 
     def trunks(self):
-        return (self.transformer_2DNet.trunk, self.transformer_3DNet.trunk)
+        return tuple(t for t in (self.transformer_2DNet.trunk, self.transformer_3DNet.trunk)
+                     if hasattr(t, "begin_scratch_running"))
 
     def encode(self, X):
         """Encoder stage only (fusion_net.py:884-885): -> (fundus tokens [B,N2,1024], OCT tokens [B,N3,768])."""
