@@ -128,7 +128,7 @@ def _w3d(w, k, ci):
     return w[..., : k * ci].reshape(co, k, k, k, ci).permute(0, 4, 3, 1, 2)
 
 
-def trunk3d_forward(x, sd, n_blocks_per_layer):
+def trunk3d_forward(x, sd, n_blocks_per_layer, train=True):
     """Oracle of encoders3d.ResNet3DTrunk (parity unpinned by the reference: no source): torch-CPU
     F.conv3d / F.batch_norm(training=True) / F.relu / F.max_pool3d in the MedicalNet-style basic-block topology.
     x [N,1,D,H,W]; sd: name -> tensor from trunk3d_state(); -> [N,512,d,h,w]."""
@@ -137,7 +137,7 @@ def trunk3d_forward(x, sd, n_blocks_per_layer):
 
     def bn(x, name):
         return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
-                            sd[name + ".bias"], True, 0.1, 1e-5)
+                            sd[name + ".bias"], train, 0.1, 1e-5)
 
     x = F.max_pool3d(F.relu(bn(conv(x, "conv1", 7, 2, 3), "bn1")), 3, 2, 1)
     bi, ci = 0, 64

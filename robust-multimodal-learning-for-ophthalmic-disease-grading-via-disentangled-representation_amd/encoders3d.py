@@ -144,8 +144,12 @@ class _Bn3d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
 
     def forward(self, raw, relu, residual=None):
-        if not self.training:
-            raise RuntimeError("ResNet3DTrunk: eval-mode BatchNorm3d is not built (training path only)")
+        if not self.training:      # inference: running statistics, nothing saved (same apply kernel as the 2-D trunk)
+            shp = raw.shape
+            out = ops.batchnorm_eval(raw.contiguous().view(-1, 1, 1, shp[-1]), self.running_mean, self.running_var,
+                                     self.weight, self.bias, 1e-5, relu,
+                                     None if residual is None else residual.contiguous().view(-1, 1, 1, shp[-1]))
+            return out.view(shp)
         self.num_batches_tracked += 1
         return BnActFn.apply(raw, self.weight, self.bias, self.running_mean, self.running_var, relu, residual)
 

@@ -90,6 +90,12 @@ def test_resnet3d_trunk_fwd_bwd_vs_oracle(edrl, dev):
     print(f"[parity] trunk3d: fwd envelope {env:.2e}, worst gradient rel err {worst:.3e}")
     assert int(trunk.bn1.num_batches_tracked) == 1
     check("trunk3d bn1.running_mean", trunk.bn1.running_mean.cpu(), sd64["bn1.running_mean"], 1e-5)
+    # inference mode: running statistics (the state after the training pass above), nothing saved
+    trunk.eval()
+    with torch.no_grad():
+        fe = trunk(x.view(2, 16, 64, 64, 1).to(dev))
+        fe_ref = RO.trunk3d_forward(x.double(), RO.trunk3d_state(trunk, requires_grad=False), layers, train=False)
+    check("trunk3d_eval_fwd", fe.cpu().permute(0, 4, 1, 2, 3), fe_ref, 1e-4)
 
 
 def test_medfusion_step_with_3d_oct_encoder(edrl, dev):
