@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_group_kernel(const float* __restrict__
     o[c] = ng; o[C + c] = mu; o[2 * C + c] = m2;
   }
 }
-__global__ __launch_bounds__(64) void bn_finalize_groups_kernel(const double* __restrict__ gin, int G, int C, long M,
+__global__ __launch_bounds__(256) void bn_finalize_groups_kernel(const double* __restrict__ gin, int G, int C, long M,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
                                                                 float* __restrict__ running_mean,
@@ -264,16 +264,22 @@ __global__ __launch_bounds__(64) void bn_finalize_groups_kernel(const double* __
                                                                 float eps, float* __restrict__ mean_out,
                                                                 float* __restrict__ rstd_out, float* __restrict__ scale,
                                                                 float* __restrict__ shift) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int gI = 0; gI < G; ++gI) s += gin[(long)gI * 3 * C + c] * gin[(long)gI * 3 * C + C + c];
-  const double mu = s / (double)M;
-  double m2 = 0.0;
-  for (int gI = 0; gI < G; ++gI) {
-    const double d = gin[(long)gI * 3 * C + C + c] - mu;
-    m2 += gin[(long)gI * 3 * C + 2 * C + c] + gin[(long)gI * 3 * C + c] * d * d;
-  }
+  // 16 channels x 16 lanes per workgroup: a lane walks every 16th group (several hundred groups for the 56x56 layers:
+  // one thread per channel was a ~50 us chain of dependent loads on the critical path of every conv+BN pair)
+  __shared__ double sh[256];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
+  double a0 = 0.0;
+  if (c < C)
+    for (int gI = q; gI < G; gI += FIN_LANES) a0 += gin[(long)gI * 3 * C + c] * gin[(long)gI * 3 * C + C + c];
+  const double mu = fin_lane_sum(a0, sh) / (double)M;
+  double a1 = 0.0;
+  if (c < C)
+    for (int gI = q; gI < G; gI += FIN_LANES) {
+      const double d = gin[(long)gI * 3 * C + C + c] - mu;
+      a1 += gin[(long)gI * 3 * C + 2 * C + c] + gin[(long)gI * 3 * C + c] * d * d;
+    }
+  const double m2 = fin_lane_sum(a1, sh);
+  if (q != 0 || c >= C) return;
   double var = m2 / (double)M;
   if (var < 0.0) var = 0.0;
   const float rs = (float)(1.0 / sqrt(var + (double)eps));
@@ -811,7 +817,7 @@ int edrl_bn_finalize_partials_f32(const float* part, long nchunks, int rows_per_
     hipLaunchKernelGGL(bn_group_kernel, dim3(edrl_cdiv(C, FIN_CH), G), dim3(256), 0, st, part, (int)nchunks, C, M,
                        rows_per_chunk, group_ws);
     EDRL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(edrl_cdiv(C, 64)), dim3(64), 0, st, group_ws, G, C, M, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, group_ws, G, C, M, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
     EDRL_LAUNCH_CHECK();
     return 0;
