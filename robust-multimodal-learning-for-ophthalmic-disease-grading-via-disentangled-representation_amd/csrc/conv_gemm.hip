@@ -510,7 +510,9 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
-      __syncthreads();
+      // each wave transposes through its OWN staging region: a wave-local fence suffices; only the statistics' shift
+      // (row 0 of another wave's region, first pass) needs the workgroup barrier
+      if (stats && i == 0) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       // shift K = the workgroup's first output row (always a valid row): it sits in row 0 of the staging region of
       // the upper wave that owns this column half; a sample of the data, so var << mean^2 costs no precision.
       if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(smem + (wave & 1) * 32 * SLD + sc4 * 4);
@@ -539,7 +541,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
           *reinterpret_cast<f32x4*>(p) = v;
         }
       }
-      __syncthreads();
+      // staging reads done before the next pass overwrites them (workgroup-wide after the pass that shared the shift row)
+      if (stats && i == 0) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (stats) {
       // lanes that share the channel group (same sc4) differ by multiples of C4: butterfly over those lane bits
