@@ -12,7 +12,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_DIR = os.path.dirname(_PKG_DIR)
-LIB_PATH = os.path.join(_PKG_DIR, "libedrl_hip.so")
+LIB_PATH = os.environ.get("EDRL_LIB_PATH") or os.path.join(_PKG_DIR, "libedrl_hip.so")   # override: A/B builds
 HEADER_PATH = os.path.join(_REPO_DIR, "include", "edrl_hip.h")
 
 _CTYPE = {

@@ -510,12 +510,12 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
-      // each wave transposes through its OWN staging region: a wave-local fence suffices; only the statistics' shift
-      // (row 0 of another wave's region, first pass) needs the workgroup barrier
-      if (stats && i == 0) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      // shift K = the workgroup's first output row (always a valid row): it sits in row 0 of the staging region of
-      // the upper wave that owns this column half; a sample of the data, so var << mean^2 costs no precision.
-      if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(smem + (wave & 1) * 32 * SLD + sc4 * 4);
+      // each wave transposes through its OWN staging region: a wave-local fence suffices (no workgroup barrier)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      // shift K of the BatchNorm partials = the WAVE's first output row (row 0 of its own staging region): a sample of
+      // the data, so var << mean^2 costs no precision.  The two row halves of the tile are re-based onto the upper
+      // half's K when they are combined below.
+      if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(stage + sc4 * 4);
 #pragma unroll
       for (int t = 0; t < 32 / RPP2; ++t) {
         const int row = t * RPP2 + srow;
@@ -541,8 +541,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
           *reinterpret_cast<f32x4*>(p) = v;
         }
       }
-      // staging reads done before the next pass overwrites them (workgroup-wide after the pass that shared the shift row)
-      if (stats && i == 0) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // staging reads done before the next pass overwrites them
     }
     if (stats) {
       // lanes that share the channel group (same sc4) differ by multiples of C4: butterfly over those lane bits
@@ -551,19 +550,28 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
       }
-      float* red = smem + 4 * 32 * SLD;          // beyond the staging regions: [wave][2][WN]
+      float* red = smem + 4 * 32 * SLD;          // beyond the staging regions: [wave][3][WN] = (S1, S2, K)
       if (srow == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * WN + sc4 * 4 + e] = st0[e]; red[(wave * 2 + 1) * WN + sc4 * 4 + e] = st1[e]; }
+        for (int e = 0; e < 4; ++e) {
+          red[(wave * 3 + 0) * WN + sc4 * 4 + e] = st0[e];
+          red[(wave * 3 + 1) * WN + sc4 * 4 + e] = st1[e];
+          red[(wave * 3 + 2) * WN + sc4 * 4 + e] = kshift[e];
+        }
       }
       __syncthreads();
       if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {   // waves 0/1 own the column halves; add the lower row half (waves 2/3)
         float* pp = g.stat_part + (long)tile_m * 3 * g.NC;
+        long nl = g.M - (m0 + WM);                       // valid rows of the lower half
+        const float nb = nl <= 0 ? 0.f : (nl > WM ? (float)WM : (float)nl);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int cc = sc4 * 4 + e;
-          pp[n + e] = red[(wave * 2 + 0) * WN + cc] + red[((wave + 2) * 2 + 0) * WN + cc];
-          pp[g.NC + n + e] = red[(wave * 2 + 1) * WN + cc] + red[((wave + 2) * 2 + 1) * WN + cc];
+          const float s1b = red[((wave + 2) * 3 + 0) * WN + cc], s2b = red[((wave + 2) * 3 + 1) * WN + cc];
+          const float d = red[((wave + 2) * 3 + 2) * WN + cc] - kshift[e];      // K_lower - K_upper
+          // sum (y-Ku) = sum (y-Kl) + n d ;  sum (y-Ku)^2 = sum (y-Kl)^2 + 2 d sum (y-Kl) + n d^2
+          pp[n + e] = st0[e] + (s1b + nb * d);
+          pp[g.NC + n + e] = st1[e] + (s2b + 2.f * d * s1b + nb * d * d);
           pp[2 * g.NC + n + e] = kshift[e];
         }
       }
