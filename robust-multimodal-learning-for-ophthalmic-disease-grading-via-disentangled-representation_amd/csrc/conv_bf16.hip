@@ -237,8 +237,10 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
-    __syncthreads();
-    if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(smem + (wave & 1) * 32 * SLD + sc4 * 4);
+    // per-wave staging region and per-wave BatchNorm shift (its own first row): wave-local fences, no workgroup barrier
+    // (same scheme as conv_gemm.hip's epilogue; the row halves are re-based when combined below)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(stage + sc4 * 4);
 #pragma unroll
     for (int t = 0; t < 32 / RPP2; ++t) {
       const int row = t * RPP2 + srow;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
         *reinterpret_cast<bf16x4*>(p) = ov;
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (stats) {
 #pragma unroll
@@ -274,19 +276,27 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
 #pragma unroll
       for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
     }
-    float* red = smem + 4 * 32 * SLD;
+    float* red = smem + 4 * 32 * SLD;          // [wave][3][WN] = (S1, S2, K)
     if (srow == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * WN + sc4 * 4 + e] = st0[e]; red[(wave * 2 + 1) * WN + sc4 * 4 + e] = st1[e]; }
+      for (int e = 0; e < 4; ++e) {
+        red[(wave * 3 + 0) * WN + sc4 * 4 + e] = st0[e];
+        red[(wave * 3 + 1) * WN + sc4 * 4 + e] = st1[e];
+        red[(wave * 3 + 2) * WN + sc4 * 4 + e] = kshift[e];
+      }
     }
     __syncthreads();
     if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
       float* pp = g.stat_part + (long)tile_m * 3 * g.NC;
+      long nl = g.M - (m0 + WM);
+      const float nb = nl <= 0 ? 0.f : (nl > WM ? (float)WM : (float)nl);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int cc = sc4 * 4 + e;
-        pp[n + e] = red[(wave * 2 + 0) * WN + cc] + red[((wave + 2) * 2 + 0) * WN + cc];
-        pp[g.NC + n + e] = red[(wave * 2 + 1) * WN + cc] + red[((wave + 2) * 2 + 1) * WN + cc];
+        const float s1b = red[((wave + 2) * 3 + 0) * WN + cc], s2b = red[((wave + 2) * 3 + 1) * WN + cc];
+        const float d = red[((wave + 2) * 3 + 2) * WN + cc] - kshift[e];
+        pp[n + e] = st0[e] + (s1b + nb * d);
+        pp[g.NC + n + e] = st1[e] + (s2b + 2.f * d * s1b + nb * d * d);
         pp[2 * g.NC + n + e] = kshift[e];
       }
     }
@@ -300,7 +310,7 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   size_t lds = (size_t)2 * (128 + BN) * HLD * sizeof(__bf16);
-  const size_t epi = (size_t)(4 * 32 * (BN / 2 + 4) + 4 * 2 * (BN / 2)) * sizeof(float);
+  const size_t epi = (size_t)(4 * 32 * (BN / 2 + 4) + 4 * 3 * (BN / 2)) * sizeof(float);
   if (epi > lds) lds = epi;
   auto kern = conv_gather_bf16_kernel<BN, DGRAD, BUF>;
   static bool attr_set = false;
