@@ -166,6 +166,10 @@ def main():
                     "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                     "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
                 }
+                if enc_dtype == "bf16":
+                    res["roofline"]["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
+                                               "HBM-bound (50-250 FLOP/B against a ~450 FLOP/B ridge), only the 3x3 layers of "
+                                               "stages 2-4 are MFMA-bound (~790 TFLOP/s there): profiles/README.md")
             res["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": round(v["tflops"], 3)} for k, v in ks.items()}
         if "roofline" in res:
