@@ -362,7 +362,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int pitch, int pix
   return u.v;
 }
 
-template <int BM, int BN>
+// FASTLD: buffer-descriptor operand loads with a branch-free 32-bit pixel decode (same scheme as conv_gemm.hip's wgrad;
+// host-checked: WBK/OW + 1 <= OH, per-workgroup footprints < 2 GiB).
+template <int BM, int BN, bool FASTLD = false>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
                                                                  float* __restrict__ part, WgradGeomH g) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -414,7 +416,62 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
   bf16x8 zero8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
+  // ---- FASTLD state (byte offsets; >= 2 GiB = masked)
+  constexpr unsigned OOBW = 0x80000000u;
+  unsigned a_off[A_LD], b_roff[B_LD];
+  int b_ih[B_LD], b_iw[B_LD];
+  int ih_lim = 0, iw_lim = 0, tapconst = 0, dw_step = 0, dh_step = 0;
+  unsigned a_step = 0, c_step = 0, c_wrapw = 0, c_wraph = 0;
+  __amdgpu_buffer_rsrc_t rs_dy, rs_x;
+  if constexpr (FASTLD) {
+    const long p_lo = t_begin * WBK;
+    long p_hi = t_end * WBK; if (p_hi > g.P) p_hi = g.P;
+    long rows = p_hi - p_lo; if (rows < 1) rows = 1;
+    const unsigned ld2y = (unsigned)g.Co * 2u, ld2x = (unsigned)g.SC * 2u;
+    rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p_lo * g.Co), 0, (int)(rows * ld2y), 0x00020000);
+    const long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + n_lo * g.SH * g.SW * g.SC), 0,
+                                             (int)((n_hi - n_lo + 1) * g.SH * g.SW * ld2x), 0x00020000);
+    const int co = co0 + ac8 * 8;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      a_off[i] = co < g.Co ? (unsigned)((tid + 256 * i) / AC8) * ld2y + (unsigned)co * 2u : OOBW;
+    a_step = WBK * ld2y;
+    const int a16 = WBK / g.OW, b16 = WBK - a16 * g.OW;
+    c_step = (unsigned)(b16 * g.stride + a16 * g.stride * g.SW) * ld2x;
+    c_wrapw = (unsigned)(g.stride * g.SW - g.OW * g.stride) * ld2x;
+    c_wraph = (unsigned)(g.SH * g.SW - g.OH * g.stride * g.SW) * ld2x;
+    dw_step = b16 * g.stride; dh_step = a16 * g.stride;
+    ih_lim = g.OH * g.stride + kkh - g.pad;
+    iw_lim = g.OW * g.stride + kkw - g.pad;
+    tapconst = ((kkh - g.pad) * g.SW + (kkw - g.pad)) * (int)ld2x + kc * 2;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      b_ih[i] = boh[i] * g.stride + kkh - g.pad;
+      b_iw[i] = bow[i] * g.stride + kkw - g.pad;
+      b_roff[i] = (unsigned)(((bn_[i] - (int)n_lo) * g.SH + boh[i] * g.stride) * g.SW + bow[i] * g.stride) * ld2x;
+    }
+  }
   auto load_tile = [&]() {
+    if constexpr (FASTLD) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        a_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_off[i], 0, 0));
+        a_off[i] += a_step;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        const bool ok = kvalid && (unsigned)b_ih[i] < (unsigned)g.SH && (unsigned)b_iw[i] < (unsigned)g.SW;
+        const unsigned off = ok ? b_roff[i] + (unsigned)tapconst : OOBW;
+        b_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+        b_iw[i] += dw_step; b_ih[i] += dh_step; b_roff[i] += c_step;
+        const bool w = b_iw[i] >= iw_lim;
+        b_iw[i] -= w ? g.OW * g.stride : 0; b_ih[i] += w ? g.stride : 0; b_roff[i] += w ? c_wrapw : 0u;
+        const bool h = b_ih[i] >= ih_lim;
+        b_ih[i] -= h ? g.OH * g.stride : 0; b_roff[i] += h ? c_wraph : 0u;
+      }
+      return;
+    }
     const int co = co0 + ac8 * 8;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
@@ -438,10 +495,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
     __bf16* b = Bs + buf * WBK * PB;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<bf16x8*>(a + ((tid + 256 * i) / AC8) * PA + ac8 * 8) = a_ok[i] ? a_st[i] : zero8;
+      *reinterpret_cast<bf16x8*>(a + ((tid + 256 * i) / AC8) * PA + ac8 * 8) = (FASTLD || a_ok[i]) ? a_st[i] : zero8;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<bf16x8*>(b + ((tid + 256 * i) / BC8) * PB + bc8 * 8) = b_ok[i] ? b_st[i] : zero8;
+      *reinterpret_cast<bf16x8*>(b + ((tid + 256 * i) / BC8) * PB + bc8 * 8) = (FASTLD || b_ok[i]) ? b_st[i] : zero8;
   };
 
   f32x16 acc[TM][TN];
@@ -664,16 +721,25 @@ int edrl_conv2d_nhwc_wgrad_bf16(const void* dy, const void* x, float* dw, float*
   if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
   constexpr int BM = 128, BN = 128;
   const size_t lds = (size_t)2 * WBK * ((BM + 32) + (BN + 32)) * sizeof(__bf16);
-  auto kern = conv_wgrad_bf16_kernel<BM, BN>;
+  static const bool fast_env = []() { const char* e = getenv("EDRL_WGRAD_FAST"); return !(e && e[0] == '0'); }();
+  const long span = (long)g.tiles_per_split * WBK;
+  const bool fast = fast_env && (WBK / Wo + 1 <= Ho) && span * Co * 2 < (1L << 31) &&
+                    (span / ((long)Ho * Wo) + 2) * Hi * Wi * Ci * 2 < (1L << 31);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   g.tiles_x = edrl_cdiv(g.Ktot, BN); g.tiles_y = edrl_cdiv(Co, BM);
   const long nblk = (long)g.tiles_x * g.tiles_y * splits;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy, (const __bf16*)x, workspace, g);
+  if (fast)
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BM, BN, true>), dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy,
+                       (const __bf16*)x, workspace, g);
+  else
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BM, BN, false>), dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy,
+                       (const __bf16*)x, workspace, g);
   EDRL_LAUNCH_CHECK();
   const long n = (long)Co * g.Ktot;
   hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n, splits, accumulate);
