@@ -920,37 +920,32 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
       if (t + 1 < t_end) load_tile(t + 1);
       const float* a = As + buf * BKT * LDA + wm0 + li;
       const float* b = Bs + buf * BKT * LDB + wn0 + li;
-      // fragments for 4 k-steps are fetched ahead of the 4x(TM*TN) MFMAs that consume the previous 4
-      constexpr int KG = 4;
-      float af[2][KG][TM], bf[2][KG][TN];
+      // software pipeline over the k-steps: the fragments of step s+1 are requested BEFORE the TM*TN MFMAs of step s
+      // are issued (pinned with scheduling-group barriers: left alone the compiler issues them after, and the wave
+      // then waits out the LDS latency with an idle MFMA pipe at every step)
+      float af[2][TM], bf[2][TN];
 #pragma unroll
-      for (int q = 0; q < KG; ++q) {
-        const int k = 2 * q + lh;
+      for (int i = 0; i < TM; ++i) af[0][i] = a[lh * LDA + i * 32];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][q][i] = a[k * LDA + i * 32];
+      for (int j = 0; j < TN; ++j) bf[0][j] = b[lh * LDB + j * 32];
+      __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);     // step-0 fragments
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][q][j] = b[k * LDB + j * 32];
-      }
+      for (int sidx = 0; sidx < BKT / 2; ++sidx) {
+        const int cur = sidx & 1, nxt = cur ^ 1;
+        if (sidx + 1 < BKT / 2) {
+          const int k = 2 * (sidx + 1) + lh;
 #pragma unroll
-      for (int kg = 0; kg < BKT / 2 / KG; ++kg) {
-        const int cur = kg & 1, nxt = cur ^ 1;
-        if (kg + 1 < BKT / 2 / KG) {
+          for (int i = 0; i < TM; ++i) af[nxt][i] = a[k * LDA + i * 32];
 #pragma unroll
-          for (int q = 0; q < KG; ++q) {
-            const int k = 2 * ((kg + 1) * KG + q) + lh;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[nxt][q][i] = a[k * LDA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[nxt][q][j] = b[k * LDB + j * 32];
-          }
+          for (int j = 0; j < TN; ++j) bf[nxt][j] = b[k * LDB + j * 32];
         }
 #pragma unroll
-        for (int q = 0; q < KG; ++q)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][q][i], bf[cur][q][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        if (sidx + 1 < BKT / 2) __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // DS reads (read2 pairs)
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                             // MFMAs
       }
       if (t + 1 < t_end) store_tile(buf ^ 1);
       __syncthreads();
