@@ -40,7 +40,11 @@ for name, Ci, H, Co, k, s, p, cnt in L:
     wt = ops.permute_weight(w)
     flop = 2.0 * N * Ho * Ho * Co * k * k * Ci
     y = torch.empty(N, Ho, Ho, Co, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
-    tf = timeit(lambda: ops.conv2d_fwd(x, w, stride=s, pad=p, out=y))
+    if os.environ.get("BENCH_FWD_STATS") == "1" and Ci % 16 == 0:     # forward with the fused BatchNorm partials (as in the step)
+        shift = torch.zeros(Co, device=dev)
+        tf = timeit(lambda: ops.conv2d_fwd_stats(x, w, shift, s, p))
+    else:
+        tf = timeit(lambda: ops.conv2d_fwd(x, w, stride=s, pad=p, out=y))
     td = timeit(lambda: ops.conv2d_dgrad(dy, wt, tuple(x.shape), s, p, out=dx)) if Ci % 4 == 0 and name != "stem7x7" else float("nan")
     tw = timeit(lambda: ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p, out=dw))
     mb = (x.numel() + y.numel()) * 4 / 5e12 * 1e3
