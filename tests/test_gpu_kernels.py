@@ -30,6 +30,7 @@ CONV_CASES = [
     (5, 32, 6, 6, 64, 3, 1, 1),      # wgrad buffer-load path: two row wraps + image wraps inside one 16-pixel tile
     (3, 32, 4, 4, 64, 3, 1, 1),      # 16 pixels = one whole image: wgrad falls back to the generic decode
     (7, 64, 12, 20, 64, 3, 2, 1),    # non-square, strided, pixel count not a multiple of the tile
+    (5, 1, 75, 91, 64, 7, 2, 3),     # odd-sized OCT stem (direct 7x7 path: scalar loader, many split-K slabs)
 ]
 
 
