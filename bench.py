@@ -165,6 +165,9 @@ def main():
                     "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                     "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
+                    "launch_unit": "one C-ABI call (edrl_conv2d_nhwc_fwd*/dgrad*); a stride-2 dgrad call issues one kernel per "
+                                   "non-empty parity class (up to 4), so rocprofv3 lists ~1.4x as many, shorter kernel rows -- "
+                                   "total kernel time and TFLOP/s are the comparable figures (profiles/README.md)",
                 }
                 if enc_dtype == "bf16":
                     res["roofline"]["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
