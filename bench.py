@@ -165,15 +165,15 @@ def main():
                     "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                     "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
-                    "launch_unit": "one C-ABI call (edrl_conv2d_nhwc_fwd*/dgrad*); a stride-2 dgrad call issues one kernel per "
-                                   "non-empty parity class (up to 4), so rocprofv3 lists ~1.4x as many, shorter kernel rows -- "
-                                   "total kernel time and TFLOP/s are the comparable figures (profiles/README.md)",
+                    "launch_unit": "kernel launches as rocprofv3 counts them (a stride-2 data-gradient call issues one kernel "
+                                   "per non-empty parity class; the HIP events bracket the call); rocprofv3's conv_gather_* rows are these "
+                                   "launches plus the head's Linear layers, which run the same kernels (key linear_gather below)",
                 }
                 if enc_dtype == "bf16":
                     res["roofline"]["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
                                                "HBM-bound (50-250 FLOP/B against a ~450 FLOP/B ridge), only the 3x3 layers of "
                                                "stages 2-4 are MFMA-bound (~790 TFLOP/s there): profiles/README.md")
-            res["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
+            res["kernels"] = {k: {"launches": v["launches"], "calls": v["calls"], "ms_total": round(v["ms"], 3),
                                   "tflops": round(v["tflops"], 3)} for k, v in ks.items()}
         if "roofline" in res:
             # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py);

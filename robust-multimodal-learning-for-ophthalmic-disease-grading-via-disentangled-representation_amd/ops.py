@@ -47,17 +47,18 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def add(self, kind, flops, e0, e1):
-        r = self.records.setdefault(kind, [0.0, []])
+    def add(self, kind, flops, e0, e1, kernels=1):
+        r = self.records.setdefault(kind, [0.0, [], 0])
         r[0] += flops
         r[1].append((e0, e1))
+        r[2] += kernels
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, (flops, evs) in self.records.items():
+        for kind, (flops, evs, kernels) in self.records.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)
-            out[kind] = {"launches": len(evs), "flops": flops, "ms": ms,
+            out[kind] = {"launches": kernels, "calls": len(evs), "flops": flops, "ms": ms,
                          "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
         return out
 
@@ -70,7 +71,9 @@ def set_timer(t):
     _timer = t
 
 
-def _launch_timed(kind, flops, name, *args):
+def _launch_timed(kind, flops, name, *args, kernels=1):
+    """`kernels`: MFMA kernels the C-ABI call issues (a strided data gradient issues one per non-empty parity class),
+    so that the timer's launch count is the one rocprofv3 sees."""
     if _timer is None:
         L.call(name, *args)
         return
@@ -78,7 +81,23 @@ def _launch_timed(kind, flops, name, *args):
     e0.record()
     L.call(name, *args)
     e1.record()
-    _timer.add(kind, flops, e0, e1)
+    _timer.add(kind, flops, e0, e1, kernels)
+
+
+def _dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate):
+    """Number of gather kernels edrl_conv2d_nhwc_dgrad_* launches (mirrors its parity-class loop)."""
+    n = 0
+    for ph in range(stride):
+        for pw in range(stride):
+            h0, w0 = (ph - pad) % stride, (pw - pad) % stride
+            if h0 >= Hi or w0 >= Wi:
+                continue
+            khs = (KH - ph + stride - 1) // stride if ph < KH else 0
+            kws = (KW - pw + stride - 1) // stride if pw < KW else 0
+            if khs * kws == 0 and accumulate:
+                continue
+            n += 1
+    return n
 
 
 # ------------------------------------------------------------------ raw (non-autograd) launch helpers
@@ -186,7 +205,8 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=False):
     if out is None:
         out = torch.empty((N, Hi, Wi, Ci), device=dy.device, dtype=torch.float32)
     _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_f32", P(dy), P(wt),
-                  P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, FLAG_ACCUM if accumulate else 0)
+                  P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, FLAG_ACCUM if accumulate else 0,
+                  kernels=_dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate))
     return out
 
 
@@ -928,7 +948,8 @@ def conv2d_dgrad_bf16(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=Fal
     if out is None:
         out = torch.empty((N, Hi, Wi, Ci), device=dy.device, dtype=torch.bfloat16)
     _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bf16", P(dy), P(wt),
-                  P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0)
+                  P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0,
+                  kernels=_dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate))
     return out
 
 
