@@ -22,24 +22,54 @@ def _conv(x, sd, name, stride, pad):
     return F.conv2d(x, w[:, :x.shape[1]], stride=stride, padding=pad)
 
 
-def trunk_forward(x, sd, kind, blocks, train=True):
+def _relu(x, pins, key):
+    """ReLU, or — when `pins` holds a boolean mask for `key` — multiplication by that mask: the discrete decision is
+    taken from the product instead of from this precision's own sign test (an fp32 and an fp64 pipeline disagree on
+    the sign of a pre-activation within round-off of zero; pinning removes that one ill-conditioned bit per element
+    from a gradient comparison).  Disagreements between the pinned mask and the oracle's own sign are counted."""
+    if pins is None or key not in pins:
+        return F.relu(x)
+    m = pins[key]
+    pins.setdefault("_flips", {})[key] = int(((x.detach() > 0) != m).sum())
+    return x * m.to(x.dtype)
+
+
+def _maxpool(x, pins):
+    if pins is None or "maxpool" not in pins:
+        return F.max_pool2d(x, 3, 2, 1)
+    idx = pins["maxpool"].long()                       # [N,C,Ho,Wo], kh*3+kw of the product's arg-max
+    N, C, H, W = x.shape
+    Ho, Wo = idx.shape[2], idx.shape[3]
+    xp = F.pad(x, (1, 1, 1, 1))
+    rows = 2 * torch.arange(Ho).view(1, 1, Ho, 1) + idx // 3
+    cols = 2 * torch.arange(Wo).view(1, 1, 1, Wo) + idx % 3
+    out = xp.flatten(2).gather(2, (rows * (W + 2) + cols).flatten(2)).view(N, C, Ho, Wo)
+    own = F.max_pool2d(x.detach(), 3, 2, 1)
+    pins.setdefault("_flips", {})["maxpool"] = int((own != out.detach()).sum())
+    return out
+
+
+def trunk_forward(x, sd, kind, blocks, train=True, pins=None):
     """x NCHW -> feature map NCHW. `sd`: dict name -> tensor (parameters may require grad; running
-    stats are updated in place like nn.BatchNorm2d)."""
-    x = F.relu(_bn(_conv(x, sd, "conv1", 2, 3), sd, "bn1", train))
-    x = F.max_pool2d(x, 3, 2, 1)
+    stats are updated in place like nn.BatchNorm2d).  `pins` (optional): {conv name: bool ReLU mask NCHW, "maxpool":
+    arg-max tap index NCHW} taken from the product (see _relu)."""
+    x = _relu(_bn(_conv(x, sd, "conv1", 2, 3), sd, "bn1", train), pins, "conv1")
+    x = _maxpool(x, pins)
     for blk in blocks:
         pre, s = blk["name"], blk["stride"]
         idn = x
         if kind == "bottleneck":
-            o = F.relu(_bn(_conv(x, sd, pre + ".conv1", 1, 0), sd, pre + ".bn1", train))
-            o = F.relu(_bn(_conv(o, sd, pre + ".conv2", s, 1), sd, pre + ".bn2", train))
+            o = _relu(_bn(_conv(x, sd, pre + ".conv1", 1, 0), sd, pre + ".bn1", train), pins, pre + ".conv1")
+            o = _relu(_bn(_conv(o, sd, pre + ".conv2", s, 1), sd, pre + ".bn2", train), pins, pre + ".conv2")
             o = _bn(_conv(o, sd, pre + ".conv3", 1, 0), sd, pre + ".bn3", train)
+            last = pre + ".conv3"
         else:
-            o = F.relu(_bn(_conv(x, sd, pre + ".conv1", s, 1), sd, pre + ".bn1", train))
+            o = _relu(_bn(_conv(x, sd, pre + ".conv1", s, 1), sd, pre + ".bn1", train), pins, pre + ".conv1")
             o = _bn(_conv(o, sd, pre + ".conv2", 1, 1), sd, pre + ".bn2", train)
+            last = pre + ".conv2"
         if blk["downsample"]:
             idn = _bn(_conv(x, sd, pre + ".downsample.0", s, 0), sd, pre + ".downsample.1", train)
-        x = F.relu(o + idn)
+        x = _relu(o + idn, pins, last)
     return x
 
 

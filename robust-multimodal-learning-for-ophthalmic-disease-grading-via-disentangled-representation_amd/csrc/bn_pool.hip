@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void colstat_kernel(const TR* __restrict__ x, 
                                                       const unsigned char* __restrict__ rmask,
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, long M, int C, long ld,
-                                                      float* __restrict__ part) {
+                                                      float* __restrict__ part, TA* __restrict__ gout = nullptr) {
   __shared__ float sh[256 * 8];
   const int C4 = C >> 2;
   const int CG = C4 < 64 ? C4 : 64;  // float4 column groups per block (power of two)
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void colstat_kernel(const TR* __restrict__ x, 
             }
             s0 += g;
             s1 += g * ((xv[u] - mu) * rs);
+            if (gout) st4<TA>(gout + (r + (long)u * RL) * ld + c, g);
           }
         }
       }
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void colstat_kernel(const TR* __restrict__ x, 
           }
           s0 += g;
           s1 += g * ((xv - mu) * rs);
+          if (gout) st4<TA>(gout + r * ld + c, g);
         }
       }
     }
@@ -312,14 +314,73 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+// ---- BatchNorm backward finalize from per-tile partial sums part[chunk][planes][C] (plane 0 = sum g, plane 1 = sum g*xhat;
+// the fused data-gradient epilogue emits planes = 2 with one chunk per 128 rows, colstat_kernel<1> planes = 3 per 1024 rows).
+// -> dgamma, dbeta and bcoef [4][C] = {A = gamma*rstd, K1 = A*mean(g), K2 = A*rstd*mean(g*xhat), mean}: the coefficients the
+// consumers (conv_gemm.hip ATR 2 / DYT 2) need to form d_raw = A*g - K1 - K2*(x - mean) on the fly.
+__global__ __launch_bounds__(256) void bn_bwd_group_kernel(const float* __restrict__ part, int nchunks, int planes, int C,
+                                                           double* __restrict__ gout) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
+  const int k0 = blockIdx.y * FIN_GROUP;
+  int k1 = k0 + FIN_GROUP;
+  if (k1 > nchunks) k1 = nchunks;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C)
+    for (int k = k0 + q; k < k1; k += FIN_LANES) {
+      a0 += (double)part[((long)k * planes) * C + c];
+      a1 += (double)part[((long)k * planes + 1) * C + c];
+    }
+  const double s0 = fin_lane_sum(a0, sh), s1 = fin_lane_sum(a1, sh);
+  if (q == 0 && c < C) {
+    gout[((long)blockIdx.y * 2) * C + c] = s0;
+    gout[((long)blockIdx.y * 2 + 1) * C + c] = s1;
+  }
+}
+// groups == nullptr: reduce the float partials directly (few chunks)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_coef_kernel(const float* __restrict__ part, int nchunks, int planes,
+                                                                   const double* __restrict__ groups, int G, int C, long M,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   float* __restrict__ bcoef) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    if (groups) {
+      for (int k = q; k < G; k += FIN_LANES) { a0 += groups[((long)k * 2) * C + c]; a1 += groups[((long)k * 2 + 1) * C + c]; }
+    } else {
+      for (int k = q; k < nchunks; k += FIN_LANES) {
+        a0 += (double)part[((long)k * planes) * C + c];
+        a1 += (double)part[((long)k * planes + 1) * C + c];
+      }
+    }
+  }
+  const double s0 = fin_lane_sum(a0, sh), s1 = fin_lane_sum(a1, sh);
+  if (q != 0 || c >= C) return;
+  if (dbeta) dbeta[c] = (float)s0;
+  if (dgamma) dgamma[c] = (float)s1;
+  const float rs = rstd[c];
+  const float A = (gamma ? gamma[c] : 1.f) * rs;
+  bcoef[c] = A;
+  bcoef[C + c] = A * (float)(s0 / (double)M);
+  bcoef[2 * (long)C + c] = A * rs * (float)(s1 / (double)M);
+  bcoef[3 * (long)C + c] = mean[c];
+}
+
 // out = act((x-mean)*scale + shift + residual)
+// res_coef (optional) [4][C] = {mean, rstd, scale, shift}: the residual operand is itself a RAW conv output (the downsample
+// branch) and its BatchNorm is applied here, so the branch's normalised copy is never stored.
 template <typename TR, typename TA>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TR* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const TA* __restrict__ residual,
                                                        TA* __restrict__ out, unsigned char* __restrict__ mask_out,
-                                                       long M, int C, long ld, int relu) {
+                                                       long M, int C, long ld, int relu,
+                                                       const float* __restrict__ res_coef = nullptr) {
   const int C4 = C >> 2;
   const long total = M * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -329,8 +390,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TR* __restrict__ x,
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c);
-    f32x4 v = (xv - mu) * sc + sf;
-    if (residual) v += ld4<TA>(residual + r * ld + c);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = edrl_bn_pre(xv[e], mu[e], sc[e], sf[e]);
+    if (residual) {
+      f32x4 rv = ld4<TA>(residual + r * ld + c);
+      if (res_coef) {
+        const f32x4 rm = *reinterpret_cast<const f32x4*>(res_coef + c);
+        const f32x4 rsc = *reinterpret_cast<const f32x4*>(res_coef + 2 * (long)C + c);
+        const f32x4 rsf = *reinterpret_cast<const f32x4*>(res_coef + 3 * (long)C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[e] = edrl_bn_pre(rv[e], rm[e], rsc[e], rsf[e]);
+      }
+      v += rv;
+    }
     if (relu) {
       if (mask_out) {   // 4 ReLU sign bits per float4: the backward reads this byte instead of the 16-B activation
         int mb = 0;
@@ -860,6 +933,57 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* re
   EDRL_LAUNCH_CHECK();
   hipLaunchKernelGGL((bn_bwd_apply_kernel<float, float>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dout, out, relu_mask, x,
                      save_mean, save_rstd, gamma, coef, dx, dres, dres_accum, M, C, ld);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// BatchNorm apply whose residual operand may itself be a raw conv output with its own BatchNorm (res_fcoef [4][C] =
+// {mean, rstd, scale, shift}; NULL: the residual is used as is):  out = act((x-mean)*scale+shift + bn_r(residual)).
+int edrl_bn_apply_res_f32(const float* x, const float* fcoef, const float* residual, const float* res_fcoef, float* out,
+                          unsigned char* relu_mask, long M, int C, int relu, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3) || !x || !fcoef || !out) return EDRL_EINVAL;
+  hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, fcoef,
+                     fcoef + 2 * (long)C, fcoef + 3 * (long)C, residual, out, relu_mask, M, C, (long)C, relu, res_fcoef);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// First half of a BatchNorm(+ReLU) backward as a standalone pass (the trunk's last block, whose upstream gradient comes from
+// autograd, and the downsample branch): g = dout * relu-mask (mask bytes, optional) is written to g_out (optional) and the
+// partial sums (sum g, sum g*xhat) go to part [ceil(M/1024)][3][C] (planes = 3 for edrl_bn_bwd_finalize_partials_f32).
+int edrl_bn_bwd_reduce_f32(const float* dout, const unsigned char* relu_mask, const float* x, const float* fcoef, float* g_out,
+                           float* part, size_t part_bytes, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3) || !dout || !x || !fcoef || !part) return EDRL_EINVAL;
+  if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
+  const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL((colstat_kernel<1, float, float>), dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x, dout,
+                     (const float*)nullptr, relu_mask, fcoef, fcoef + (long)C, M, C, (long)C, part, g_out);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Second half: partial sums -> dgamma, dbeta and the coefficients bcoef [4][C] = {A, K1, K2, mean} from which the fused conv
+// kernels form d_raw = A*g - K1 - K2*(x - mean) in their operand loads.  group_ws: nchunks/64 x 2 x C doubles.
+size_t edrl_bn_bwd_group_ws_bytes(long nchunks, int C) {
+  return (size_t)((nchunks + FIN_GROUP - 1) / FIN_GROUP) * 2 * C * sizeof(double);
+}
+int edrl_bn_bwd_finalize_partials_f32(const float* part, long nchunks, int planes, long M, int C, const float* gamma,
+                                      const float* fcoef, float* dgamma, float* dbeta, float* bcoef, double* group_ws,
+                                      size_t group_ws_bytes, hipStream_t st) {
+  if (M <= 0 || C <= 0 || nchunks <= 0 || nchunks > 0x7fffffffL || (planes != 2 && planes != 3) || !part || !fcoef || !bcoef)
+    return EDRL_EINVAL;
+  const double* groups = nullptr;
+  int G = 0;
+  if (nchunks > 2 * FIN_GROUP) {
+    if (!group_ws || group_ws_bytes < edrl_bn_bwd_group_ws_bytes(nchunks, C)) return EDRL_ENOSPC;
+    G = (int)((nchunks + FIN_GROUP - 1) / FIN_GROUP);
+    hipLaunchKernelGGL(bn_bwd_group_kernel, dim3(edrl_cdiv(C, FIN_CH), G), dim3(256), 0, st, part, (int)nchunks, planes, C,
+                       group_ws);
+    EDRL_LAUNCH_CHECK();
+    groups = group_ws;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, part, (int)nchunks, planes,
+                     groups, G, C, M, gamma, fcoef, fcoef + (long)C, dgamma, dbeta, bcoef);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

@@ -21,6 +21,7 @@
 // tile t+1's loads are issued before tile t's MFMAs and written after them.
 #include "edrl_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #define BK 32
 #define LDK (BK + 4)
@@ -241,10 +242,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // through a per-workgroup descriptor based at the first image the tile's rows touch -- so masked rows / taps are an
 // out-of-range 32-bit offset that the range check zero-fills: no 64-bit address arithmetic, no selects on the address
 // or on the data, one add per staged piece and tile.
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false>
+//
+// Fused BatchNorm (BUF only; conv_geom.h GatherFuse):
+//   ATR 1: the gathered operand is a RAW conv output and the activation relu((x-mean)*scale+shift) is formed while the
+//          tile is staged to LDS (padding taps / rows >= M stay exactly 0) -- the producing layer's BatchNorm-apply pass
+//          and its activated copy never exist.
+//   ATR 2: the gathered operand is the BatchNorm-backward result d_raw = A*g - K1 - K2*(x - mean) formed from the masked
+//          upstream gradient g (src) and the raw conv output x (src2) -- no bn_bwd_apply pass, d_raw never stored.
+//   EPI 1: (data gradient) the tile just computed is the gradient of a BatchNorm+ReLU output: the epilogue masks it with
+//          the ReLU decision (sign bytes, or recomputed from the raw tensor), stores the masked gradient and emits the
+//          per-tile partial sums (sum g, sum g*xhat) of that BatchNorm's backward -- no separate reduction pass.
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
-    const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n) {
+    const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherFuse F) {
+  static_assert(ATR == 0 || BUF, "operand transforms ride on the buffer-descriptor path");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDKT = BKT + 4;
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   // ---- BUF state: byte offsets into the two descriptors; >= 2 GiB = masked (stays masked under the per-tile adds)
   constexpr unsigned OOB = 0x80000000u;
   unsigned aoff[A_LD], boff[B_LD], wrow4[B_LD];
-  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  __amdgpu_buffer_rsrc_t rs_a, rs_b, rs_a2;
   int n_first = 0;
   int cb = 0;          // uniform part of c (c = cb + k4 while FAST)
   if constexpr (BUF) {
@@ -312,6 +324,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const unsigned a_bytes = (unsigned)(((long)(n_last - n_first + 1) * g.SH * g.SW - 1) * g.ld_src * 4 + (long)g.SC * 4);
     rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
     rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, (int)((long)g.NC * g.Kfull * 4), 0x00020000);
+    if constexpr (ATR == 2)
+      rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)F.src2 + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int n = n0 + r0 + RPP * i;
@@ -376,11 +390,15 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   };
 
   f32x4 a_st[A_LD], b_st[B_LD];
+  f32x4 a_st2[ATR == 2 ? A_LD : 1];      // ATR 2: the raw conv output paired with the gradient in a_st
+  f32x4 tp0, tp1, tp2, tp3;              // per-channel transform parameters of the staged K tile (channels cb+k4 .. +3)
   bool a_ok[A_LD], b_ok[B_LD];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_piece = [&](int i) {
     if constexpr (BUF) {
       a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)aoff[i], 0, 0));
+      if constexpr (ATR == 2) a_st2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, (int)aoff[i], 0, 0));
+      if constexpr (ATR != 0) a_ok[i] = (int)aoff[i] >= 0;   // masked rows / padding taps / past-the-end tiles: offset >= 2 GiB
       if (i < B_LD) b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)boff[i], 0, 0));
       return;
     }
@@ -420,12 +438,32 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
       b_st[i] = ok ? v : zero4;
     }
   };
+  // The per-channel parameters of the staged tile are fetched late (before the LAST MFMA chunk of the running tile, ~1000
+  // cycles ahead of their use in store_tile) so that they are not live across the whole chain (VGPR budget at 3 per CU).
+  auto load_params = [&]() {
+    if constexpr (ATR != 0) {
+      const int c = cb + k4;             // < SC always (cb < SC, SC % BKT == 0)
+      tp0 = *reinterpret_cast<const f32x4*>(F.ap0 + c);
+      tp1 = *reinterpret_cast<const f32x4*>(F.ap1 + c);
+      tp2 = *reinterpret_cast<const f32x4*>(F.ap2 + c);
+      if constexpr (ATR == 2) tp3 = *reinterpret_cast<const f32x4*>(F.ap3 + c);
+    }
+  };
   auto store_tile = [&](int buf) {
     float* a = As + buf * BM * LDKT;
     float* b = Bs + buf * BN * LDKT;
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = (!FAST || BUF || a_ok[i]) ? a_st[i] : zero4;
+    for (int i = 0; i < A_LD; ++i) {
+      f32x4 v = (!FAST || BUF || a_ok[i]) ? a_st[i] : zero4;
+      if constexpr (ATR == 1) {          // tp0 = mean, tp1 = scale, tp2 = shift
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a_ok[i] ? edrl_bn_relu(v[e], tp0[e], tp1[e], tp2[e]) : 0.f;
+      } else if constexpr (ATR == 2) {   // tp0 = A, tp1 = K1, tp2 = K2, tp3 = mean
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a_ok[i] ? edrl_bn_bwd_dx(v[e], a_st2[i][e], tp0[e], tp1[e], tp2[e], tp3[e]) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       *reinterpret_cast<f32x4*>(b + (r0 + RPP * i) * LDKT + k4) = (!FAST || BUF || b_ok[i]) ? b_st[i] : zero4;
@@ -442,6 +480,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   const int KT = (g.Ktot + BKT - 1) / BKT;
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) load_piece(i);
+  load_params();
   store_tile(0);
   __syncthreads();
 
@@ -475,6 +514,9 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
         for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDKT + (kc + 1) * 8);
       }
       if (!FAST) load_piece(kc);
+      if constexpr (ATR != 0) {
+        if (kc == BKT / 8 - 1) { __builtin_amdgcn_sched_barrier(0); load_params(); __builtin_amdgcn_sched_barrier(0); }
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -501,8 +543,20 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const int n = n0 + wn0 + sc4 * 4;
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (bias && n < g.NC) bv4 = *reinterpret_cast<const f32x4*>(bias + n);
-    const bool stats = (g.flags & GF_STATS) != 0;
+    const bool stats = EPI == 0 && (g.flags & GF_STATS) != 0;
     f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
+    // EPI 1: BatchNorm(+ReLU) backward of the tensor this tile is the gradient of (channels n .. n+3 of this lane)
+    f32x4 e_mean = zero4, e_rstd = zero4, e_scale = zero4, e_shift = zero4;
+    if constexpr (EPI == 1) {
+      if (n < g.NC) {
+        e_mean = *reinterpret_cast<const f32x4*>(F.ep_mean + n);
+        e_rstd = *reinterpret_cast<const f32x4*>(F.ep_rstd + n);
+        if (!F.ep_mask) {
+          e_scale = *reinterpret_cast<const f32x4*>(F.ep_scale + n);
+          e_shift = *reinterpret_cast<const f32x4*>(F.ep_shift + n);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -538,10 +592,50 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
           if (mul) v *= *reinterpret_cast<const f32x4*>(mul + pix * g.ld_aux + n);
           float* p = dst + pix * g.ld_dst + n;
           if (accum) v += *reinterpret_cast<const f32x4*>(p);
+          if constexpr (EPI == 1) {
+            const f32x4 xr = *reinterpret_cast<const f32x4*>((const float*)F.ep_x + pix * F.ld_ep + n);
+            if (F.ep_mask) {
+              const int mb = F.ep_mask[pix * (long)(g.NC >> 2) + (n >> 2)];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (mb >> e) & 1 ? v[e] : 0.f;
+            } else if (g.flags & GF_EPI_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = edrl_bn_pre(xr[e], e_mean[e], e_scale[e], e_shift[e]) > 0.f ? v[e] : 0.f;
+            }
+            st0 += v;
+            st1 += v * ((xr - e_mean) * e_rstd);
+          }
           *reinterpret_cast<f32x4*>(p) = v;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // staging reads done before the next pass overwrites them
+    }
+    if constexpr (EPI == 1) {
+      // (sum g, sum g*xhat) of the tile's valid rows -> F.ep_part[chunk0 + tile_m][2][NC]
+#pragma unroll
+      for (int o = 32; o >= C4; o >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
+      }
+      float* red = smem + 4 * 32 * SLD;          // [wave][2][WN]
+      if (srow == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[(wave * 2 + 0) * WN + sc4 * 4 + e] = st0[e];
+          red[(wave * 2 + 1) * WN + sc4 * 4 + e] = st1[e];
+        }
+      }
+      __syncthreads();
+      if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
+        float* pp = F.ep_part + ((long)F.ep_chunk0 + tile_m) * 2 * g.NC;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = sc4 * 4 + e;
+          pp[n + e] = st0[e] + red[((wave + 2) * 2 + 0) * WN + cc];
+          pp[g.NC + n + e] = st1[e] + red[((wave + 2) * 2 + 1) * WN + cc];
+        }
+      }
+      return;
     }
     if (stats) {
       // lanes that share the channel group (same sc4) differ by multiples of C4: butterfly over those lane bits
@@ -609,23 +703,46 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   }
 }
 
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false>
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
-                            const float* mul, const GatherGeom& g, hipStream_t st) {
+                            const float* mul, const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
   const long nblk = (long)tiles_m * tiles_n;
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF>;
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, g, tiles_n);
+  GatherFuse F;
+  if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, g, tiles_n, F);
   EDRL_LAUNCH_CHECK();
   return 0;
+}
+
+// The fused-BatchNorm variants exist on the buffer-descriptor fast path only: report whether a geometry qualifies.
+static bool gather_fused_ok(const float* src, const float* wm, const float* dst, const GatherGeom& g) {
+  const long ohw = (long)g.OHs * g.OWs;
+  return (g.SC % 16 == 0) && (g.ld_src % 4 == 0) && (g.Kfull % 4 == 0) && (g.NC % 4 == 0) && (g.ld_dst % 4 == 0) &&
+         ((((uintptr_t)src | (uintptr_t)wm | (uintptr_t)dst) & 15) == 0) && ohw > 0 &&
+         (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) && (long)g.NC * g.Kfull * 4 < (1L << 31) &&
+         g.M < (1L << 31);
+}
+#define FUSED_OCC 3
+template <bool DGRAD, int ATR, int EPI>
+static int dispatch_gather_fused(const float* src, const float* wm, float* dst, const GatherGeom& g0, const GatherFuse& F,
+                                 hipStream_t st) {
+  if (!gather_fused_ok(src, wm, dst, g0)) return EDRL_EINVAL;
+  GatherGeom g = g0;
+  g.flags |= GF_VEC_EPI;
+  static const int small_grid = []() { const char* e = getenv("EDRL_NARROW_BELOW"); return e ? atoi(e) : 512; }();
+  const bool narrow = g.NC <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(g.NC, 128) < small_grid);
+  if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI>(src, wm, dst, nullptr, nullptr, g, st, &F);
+  return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI>(src, wm, dst, nullptr, nullptr, g, st, &F);
 }
 
 template <int BM, int BN, bool DGRAD, bool VEC>
@@ -711,9 +828,20 @@ struct WgradGeom {
 // buffer loads through per-block descriptors whose range check zero-fills every out-of-range row, so the loop carries
 // no 64-bit address arithmetic, no zero-selects and no loops in the pixel decode: per staged row a 32-bit running
 // offset advanced by constants (one tile = BKT output pixels) with two branch-free wrap corrections.
-template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false>
+// Fused BatchNorm operands (FASTLD only; WgradFuse):
+//   DYT 2: dY = A*g - K1 - K2*(yraw - mean) is formed from the masked gradient g (`dy`) and the raw conv output (F.dy2)
+//          while the tile is staged (the BatchNorm-backward apply pass and the d_raw tensor never exist);
+//   XT 1:  the im2col operand is relu((xraw - mean)*scale + shift) of the RAW previous conv output (`x`).
+// Rows outside the split's pixel range / padding taps are forced to exactly 0 after the transform.
+struct WgradFuse {
+  const float* dy2;                 // DYT 2: raw conv output of this layer (same geometry as dy)
+  const float* bcoef;               // DYT 2: [4][Co] = A, K1, K2, mean
+  const float* xcoef;               // XT 1:  [4][SC] = mean, rstd, scale, shift of the producing BatchNorm
+};
+template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g) {
+    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g, WgradFuse F) {
+  static_assert((DYT == 0 && XT == 0) || FASTLD, "operand transforms ride on the buffer-descriptor path");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_LD = (BM * BKT / 4) / 256, B_LD = (BN * BKT / 4) / 256;
@@ -773,7 +901,12 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   int ih_lim = 0, iw_lim = 0, tapconst = 0;
   unsigned a_step = 0, c_step = 0, c_wrapw = 0, c_wraph = 0;
   int dw_step = 0, dh_step = 0;
-  __amdgpu_buffer_rsrc_t rs_dy, rs_x;
+  __amdgpu_buffer_rsrc_t rs_dy, rs_x, rs_dy2;
+  unsigned dy_last = 0, x_last = 0;            // last in-range 16-byte offset of each descriptor
+  f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;   // DYT 2 parameters of this thread's 4 output channels
+  f32x4 xm = q0, xs = q0, xb = q0;                              // XT 1 parameters of this thread's 4 input channels
+  bool a_ok[A_LD], b_ok[B_LD];
+  f32x4 a2_st[DYT == 2 ? A_LD : 1];
   if constexpr (FASTLD) {
     const long p_lo = t_begin * BKT;
     long p_hi = t_end * BKT; if (p_hi > g.P) p_hi = g.P;
@@ -781,10 +914,29 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const unsigned ld4y = (unsigned)(g.ld_dy * 4), ld4x = (unsigned)(g.ld_x * 4);
     const unsigned dy_bytes = (unsigned)((rows - 1) * ld4y + (unsigned)g.Co * 4u);
     rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p_lo * g.ld_dy), 0, (int)dy_bytes, 0x00020000);
+    dy_last = dy_bytes - 16u;
+    if constexpr (DYT == 2) {
+      rs_dy2 = __builtin_amdgcn_make_buffer_rsrc((void*)(F.dy2 + p_lo * g.ld_dy), 0, (int)dy_bytes, 0x00020000);
+      const int co = co0 + ac4 * 4;
+      if (co < g.Co) {
+        q0 = *reinterpret_cast<const f32x4*>(F.bcoef + co);
+        q1 = *reinterpret_cast<const f32x4*>(F.bcoef + g.Co + co);
+        q2 = *reinterpret_cast<const f32x4*>(F.bcoef + 2 * g.Co + co);
+        q3 = *reinterpret_cast<const f32x4*>(F.bcoef + 3 * g.Co + co);
+      }
+    }
+    if constexpr (XT == 1) {
+      if (kvalid) {
+        xm = *reinterpret_cast<const f32x4*>(F.xcoef + kc);
+        xs = *reinterpret_cast<const f32x4*>(F.xcoef + 2 * g.SC + kc);
+        xb = *reinterpret_cast<const f32x4*>(F.xcoef + 3 * g.SC + kc);
+      }
+    }
     const long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
     const long imgs = n_hi - n_lo + 1;
     const unsigned x_bytes = (unsigned)((imgs * g.SH * g.SW - 1) * ld4x + (unsigned)g.SC * 4u);
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + n_lo * g.SH * g.SW * g.ld_x), 0, (int)x_bytes, 0x00020000);
+    x_last = x_bytes - 16u;
     const int co = co0 + ac4 * 4;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
@@ -809,6 +961,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_off[i], 0, 0));
+      if constexpr (DYT == 2) {
+        a2_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy2, (int)a_off[i], 0, 0));
+        a_ok[i] = a_off[i] <= dy_last;       // the hardware range check, restated: rows past the split / channels >= Co
+      }
       a_off[i] += a_step;
     }
 #pragma unroll
@@ -816,6 +972,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
       const bool ok = kvalid && (unsigned)b_ih[i] < (unsigned)g.SH && (unsigned)b_iw[i] < (unsigned)g.SW;
       const unsigned off = ok ? b_roff[i] + (unsigned)tapconst : OOB;
       b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+      if constexpr (XT == 1) b_ok[i] = off <= x_last;
       b_iw[i] += dw_step; b_ih[i] += dh_step; b_roff[i] += c_step;
       const bool w = b_iw[i] >= iw_lim;
       b_iw[i] -= w ? g.OW * g.stride : 0; b_ih[i] += w ? g.stride : 0; b_roff[i] += w ? c_wrapw : 0u;
@@ -893,12 +1050,22 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int row = (tid + 256 * i) / AC4;
-      *reinterpret_cast<f32x4*>(a + row * LDA + ac4 * 4) = a_st[i];
+      f32x4 v = a_st[i];
+      if constexpr (DYT == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a_ok[i] ? edrl_bn_bwd_dx(v[e], a2_st[i][e], q0[e], q1[e], q2[e], q3[e]) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a + row * LDA + ac4 * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int row = (tid + 256 * i) / BC4;
-      *reinterpret_cast<f32x4*>(b + row * LDB + bc4 * 4) = b_st[i];
+      f32x4 v = b_st[i];
+      if constexpr (XT == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = b_ok[i] ? edrl_bn_relu(v[e], xm[e], xs[e], xb[e]) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(b + row * LDB + bc4 * 4) = v;
     }
   };
 
@@ -997,11 +1164,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 #define WG_BK 16
 #define WG_OCC 4
-template <int BM, int BN, bool VEC, bool FASTLD = false>
+#define WG_OCC_FUSED 3
+template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
-                        hipStream_t st) {
+                        hipStream_t st, const WgradFuse* fuse = nullptr) {
   const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, WG_OCC, FASTLD>;
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (DYT || XT) ? WG_OCC_FUSED : WG_OCC, FASTLD, DYT, XT>;
+  WgradFuse F;
+  if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1011,7 +1181,7 @@ static int launch_wgrad(const float* dy, const float* x, float* part, const Wgra
   gg.tiles_x = edrl_cdiv(g.Ktot, BN); gg.tiles_y = edrl_cdiv(g.Co, BM);
   const long nblk = (long)gg.tiles_x * gg.tiles_y * splits;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, x, part, gg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, x, part, gg, F);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
@@ -1145,11 +1315,31 @@ size_t edrl_conv2d_nhwc_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co, int
   return (size_t)splits * Co * KH * KW * Ci * sizeof(float);
 }
 
+}  // extern "C"
+
 // Convolution weight gradient: dw[co,kh,kw,ci] (+)= sum_pix dy[pix,co] * x[pix @ tap, ci]
-int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace,
-                               size_t workspace_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
-                               int Co, int KH, int KW, int stride, int pad, long ld_dy, long ld_x,
-                               int accumulate, hipStream_t st) {
+static bool wgrad_fast_ok(const float* dy, const float* x, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, long ld_dy, long ld_x,
+                          int tiles_per_split) {
+  const bool vec = (Ci % 4 == 0) && (ld_x % 4 == 0) && (Co % 4 == 0) && (ld_dy % 4 == 0) &&
+                   (((uintptr_t)dy & 15) == 0) && (((uintptr_t)x & 15) == 0);
+  // buffer-load path: decode wraps at most once per tile, per-block operand footprints addressable with 31 bits
+  const long span = (long)tiles_per_split * WG_BK;
+  return vec && (WG_BK / Wo + 1 <= Ho) && span * ld_dy * 4 < (1L << 31) &&
+         (span / ((long)Ho * Wo) + 2) * Hi * Wi * ld_x * 4 < (1L << 31);
+}
+
+template <int DYT, int XT>
+static int wgrad_fused_launch(const float* dy, const float* x, float* ws, const WgradGeom& g, int bm, int bn, int splits,
+                              const WgradFuse& F, hipStream_t st) {
+  if (bm == 64 && bn == 64) return launch_wgrad<64, 64, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
+  if (bm == 64) return launch_wgrad<64, 128, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
+  if (bn == 64) return launch_wgrad<128, 64, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
+  return launch_wgrad<128, 128, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
+}
+
+static int wgrad_impl(const float* dy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int N, int Hi,
+                      int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, long ld_dy, long ld_x,
+                      int accumulate, const WgradFuse* fuse, hipStream_t st) {
   if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 ||
       ld_dy < Co || ld_x < Ci)
     return EDRL_EINVAL;
@@ -1164,13 +1354,18 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
   if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
   const bool vec = (Ci % 4 == 0) && (ld_x % 4 == 0) && (Co % 4 == 0) && (ld_dy % 4 == 0) &&
                    (((uintptr_t)dy & 15) == 0) && (((uintptr_t)x & 15) == 0);
-  // buffer-load path: decode wraps at most once per tile, per-block operand footprints addressable with 31 bits
   static const bool fast_env = []() { const char* e = getenv("EDRL_WGRAD_FAST"); return !(e && e[0] == '0'); }();
-  const long span = (long)g.tiles_per_split * WG_BK;
-  const bool fast = vec && fast_env && (WG_BK / Wo + 1 <= Ho) && span * ld_dy * 4 < (1L << 31) &&
-                    (span / ((long)Ho * Wo) + 2) * Hi * Wi * ld_x * 4 < (1L << 31);
+  const bool fast_ok = wgrad_fast_ok(dy, x, Hi, Wi, Ci, Ho, Wo, Co, ld_dy, ld_x, g.tiles_per_split);
+  const bool fast = fast_ok && fast_env;
   int rc;
-  if (fast) {
+  if (fuse) {
+    if (!fast_ok) return EDRL_EINVAL;     // the fused operands exist on the buffer-load path only
+    const bool dyt = fuse->dy2 != nullptr, xt = fuse->xcoef != nullptr;
+    if (dyt && (((uintptr_t)fuse->dy2 & 15) != 0)) return EDRL_EINVAL;
+    if (dyt && xt) rc = wgrad_fused_launch<2, 1>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
+    else if (dyt) rc = wgrad_fused_launch<2, 0>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
+    else return EDRL_EINVAL;
+  } else if (fast) {
     if (bm == 64 && bn == 64) rc = launch_wgrad<64, 64, true, true>(dy, x, workspace, g, splits, st);
     else if (bm == 64) rc = launch_wgrad<64, 128, true, true>(dy, x, workspace, g, splits, st);
     else if (bn == 64) rc = launch_wgrad<128, 64, true, true>(dy, x, workspace, g, splits, st);
@@ -1193,6 +1388,148 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
                      splits, accumulate);
   EDRL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" {
+int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace,
+                               size_t workspace_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
+                               int Co, int KH, int KW, int stride, int pad, long ld_dy, long ld_x,
+                               int accumulate, hipStream_t st) {
+  return wgrad_impl(dy, x, dw, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, ld_dy, ld_x,
+                    accumulate, nullptr, st);
+}
+
+// Weight gradient with the BatchNorm passes on either side folded into the operand loads (dense NHWC tensors):
+//   dY = A*g - K1 - K2*(yraw - mean)      g = masked gradient of this layer's BatchNorm output, yraw = this layer's raw conv
+//                                          output, bcoef [4][Co] = {A, K1, K2, mean} (edrl_bn_bwd_finalize_partials_f32)
+//   X  = relu((x - mean)*scale + shift)    when x_fcoef [4][Ci] = {mean, rstd, scale, shift} of the PREVIOUS layer's BatchNorm
+//                                          is given (x is then that layer's raw conv output); x as is when x_fcoef == NULL
+// Needs the buffer-load fast path (edrl_conv2d_fused_ok_f32): -22 otherwise.
+int edrl_conv2d_nhwc_wgrad_bn_f32(const float* g, const float* yraw, const float* bcoef, const float* x,
+                                  const float* x_fcoef, float* dw, float* workspace, size_t workspace_bytes, int N, int Hi,
+                                  int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int accumulate,
+                                  hipStream_t st) {
+  if (!g || !yraw || !bcoef || !x) return EDRL_EINVAL;
+  WgradFuse F;
+  F.dy2 = yraw; F.bcoef = bcoef; F.xcoef = x_fcoef;
+  return wgrad_impl(g, x, dw, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, accumulate,
+                    &F, st);
+}
+
+// ---- fused-BatchNorm forward / data gradient (dense NHWC tensors; conv_geom.h GatherFuse)
+// Forward conv whose INPUT is the raw conv output of the previous layer: a = relu((x - mean)*scale + shift) with
+// in_fcoef [4][Ci] = {mean, rstd, scale, shift} (edrl_bn_finalize_partials_f32) is formed in the operand load, and the
+// BatchNorm chunk partials of the OUTPUT are emitted like edrl_conv2d_nhwc_fwd_stats_f32.
+int edrl_conv2d_nhwc_fwd_bnin_stats_f32(const float* x, const float* in_fcoef, const float* w, float* y, float* stat_part,
+                                        size_t stat_part_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                        int KW, int stride, int pad, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+      pad < 0 || (Ci % 16) || (Co % 4) || !stat_part || !in_fcoef)
+    return EDRL_EINVAL;
+  if ((long)N * Ho * Wo > 0x7fffffffL) return EDRL_EINVAL;
+  if (stat_part_bytes < (size_t)edrl_conv_stats_chunks(N, Ho, Wo) * 3 * Co * sizeof(float)) return EDRL_ENOSPC;
+  GatherGeom g;
+  g.M = (int)((long)N * Ho * Wo);
+  g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_src = Ci; g.ld_dst = Co; g.ld_aux = 0; g.flags = GF_STATS;
+  g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
+  g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
+  g.stat_part = stat_part; g.stat_shift = nullptr;
+  GatherFuse F;
+  memset(&F, 0, sizeof(F));
+  F.ap0 = in_fcoef; F.ap1 = in_fcoef + 2 * (long)Ci; F.ap2 = in_fcoef + 3 * (long)Ci;
+  return dispatch_gather_fused<false, 1, 0>(x, w, y, g, F, st);
+}
+
+// Chunks (128-row tiles, summed over the parity classes of a strided layer) of the partial sums the fused data gradient emits.
+long edrl_conv_dgrad_bn_chunks(int N, int Hi, int Wi, int stride, int pad) {
+  long chunks = 0;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      const int h0 = ((ph - pad) % stride + stride) % stride, w0 = ((pw - pad) % stride + stride) % stride;
+      const long ohs = h0 < Hi ? (Hi - h0 + stride - 1) / stride : 0, ows = w0 < Wi ? (Wi - w0 + stride - 1) / stride : 0;
+      chunks += ((long)N * ohs * ows + 127) / 128;
+    }
+  return chunks;
+}
+
+// Data gradient with the BatchNorm-backward passes on both sides folded in:
+//   operand   dY = A*g - K1 - K2*(yraw - mean), bcoef [4][Co] = {A, K1, K2, mean}
+//   epilogue  (ep_raw != NULL) dx is the gradient of relu?(bn(ep_raw)) of the layer below: it is masked with ep_mask (sign
+//             bytes [pixel][Ci/4]) or, when ep_mask == NULL and ep_relu, with the decision recomputed from ep_raw and
+//             ep_fcoef [4][Ci] = {mean, rstd, scale, shift}; the masked gradient is stored and (sum g, sum g*xhat) per
+//             128-row tile go to ep_part [edrl_conv_dgrad_bn_chunks][2][Ci].
+//   flags     GF_ACCUM (2): dx += (before masking / reduction).
+int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g_in, const float* yraw, const float* bcoef, const float* wt, float* dx, int N,
+                                  int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                  int flags, const float* ep_raw, const unsigned char* ep_mask, const float* ep_fcoef,
+                                  int ep_relu, float* ep_part, size_t ep_part_bytes, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || !g_in || !yraw ||
+      !bcoef || (Co % 16) || (Ci % 4))
+    return EDRL_EINVAL;
+  if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
+  if (ep_raw && (!ep_fcoef || !ep_part)) return EDRL_EINVAL;
+  if (ep_raw && ep_part_bytes < (size_t)edrl_conv_dgrad_bn_chunks(N, Hi, Wi, stride, pad) * 2 * Ci * sizeof(float))
+    return EDRL_ENOSPC;
+  int sshift = 0;
+  while ((1 << sshift) < stride) ++sshift;
+  if ((1 << sshift) != stride) return EDRL_EINVAL;
+  GatherGeom g;
+  g.OH = Hi; g.OW = Wi; g.NC = Ci; g.SH = Ho; g.SW = Wo; g.SC = Co;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Kfull = KH * KW * Co;
+  g.ld_src = Co; g.ld_dst = Ci; g.ld_aux = 0;
+  g.flags = (flags & GF_ACCUM) | ((ep_raw && !ep_mask && ep_relu) ? GF_EPI_RELU : 0);
+  g.step = stride; g.kstep = stride; g.sshift = sshift;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
+  GatherFuse F;
+  memset(&F, 0, sizeof(F));
+  F.src2 = yraw;
+  F.ap0 = bcoef; F.ap1 = bcoef + (long)Co; F.ap2 = bcoef + 2 * (long)Co; F.ap3 = bcoef + 3 * (long)Co;
+  if (ep_raw) {
+    F.ep_x = ep_raw; F.ld_ep = Ci; F.ep_mask = ep_mask;
+    F.ep_mean = ep_fcoef; F.ep_rstd = ep_fcoef + (long)Ci; F.ep_scale = ep_fcoef + 2 * (long)Ci; F.ep_shift = ep_fcoef + 3 * (long)Ci;
+    F.ep_part = ep_part;
+  }
+  int chunk0 = 0;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      g.h0 = ((ph - pad) % stride + stride) % stride;
+      g.w0 = ((pw - pad) % stride + stride) % stride;
+      g.OHs = g.h0 < Hi ? (Hi - g.h0 + stride - 1) / stride : 0;
+      g.OWs = g.w0 < Wi ? (Wi - g.w0 + stride - 1) / stride : 0;
+      if (g.OHs == 0 || g.OWs == 0) continue;
+      g.kh0 = ph; g.kw0 = pw;
+      g.KHs = ph < KH ? (KH - ph + stride - 1) / stride : 0;
+      g.KWs = pw < KW ? (KW - pw + stride - 1) / stride : 0;
+      g.Ktot = g.KHs * g.KWs * Co;
+      g.M = (int)((long)N * g.OHs * g.OWs);
+      // a class no tap reaches: dx keeps its value when accumulating and nothing is reduced; otherwise the kernel still runs
+      // (zero fill, or mask + reduce the accumulated gradient)
+      if (g.Ktot == 0 && (flags & GF_ACCUM) && !ep_raw) continue;
+      F.ep_chunk0 = chunk0;
+      const int rc = ep_raw ? dispatch_gather_fused<true, 2, 1>(g_in, wt, dx, g, F, st)
+                            : dispatch_gather_fused<true, 2, 0>(g_in, wt, dx, g, F, st);
+      if (rc) return rc;
+      chunk0 += (g.M + 127) / 128;
+    }
+  return 0;
+}
+
+// 1 when every fused variant (forward operand transform, data gradient, weight gradient) has its fast path for this layer
+// geometry with dense, 16-byte-aligned tensors; the host side (encoders.py) falls back to the separate BatchNorm passes if not.
+int edrl_conv2d_fused_ok_f32(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || (Ci % 16) || (Co % 16) || (stride != 1 && stride != 2)) return 0;
+  if ((long)N * Hi * Wi > 0x7fffffffL || (long)N * Ho * Wo > 0x7fffffffL) return 0;
+  const long kfull = (long)KH * KW * Ci;
+  // forward gather: source = input, rows = output pixels
+  if (!((128 / ((long)Ho * Wo) + 2) * Hi * Wi * Ci * 4 < (1L << 31) && (long)Co * kfull * 4 < (1L << 31))) return 0;
+  // data gradient: source = output-gradient, rows = input pixels of one parity class (>= 1 pixel per image)
+  const long cls = ((long)(Hi + stride - 1) / stride) * ((Wi + stride - 1) / stride);
+  if (!((128 / (cls > 0 ? cls : 1) + 2 + 1) * Ho * Wo * Co * 4 < (1L << 31))) return 0;
+  int bm, bn, splits, tps;
+  wgrad_plan((long)N * Ho * Wo, Co, (int)kfull, KH * KW, &bm, &bn, &splits, &tps);
+  return wgrad_fast_ok((const float*)nullptr, (const float*)nullptr, Hi, Wi, Ci, Ho, Wo, Co, Co, Ci, tps) ? 1 : 0;
 }
 
 // in [A][B][C] -> out [C][B][A]   (weight [Co][taps][Ci] -> [Ci][taps][Co]; B=1 gives a matrix transpose)

@@ -27,7 +27,26 @@ struct GatherGeom {
   const float* stat_shift;
 };
 
+// Fused-BatchNorm operands of the gather kernels (conv_gather_*_kernel<..., ATR, EPI>).
+struct GatherFuse {
+  const void* src2;            // ATR 2: raw conv output paired with the masked gradient in `src` (same geometry and ld)
+  const float* ap0;            // ATR 1: mean   | ATR 2: A  = gamma*rstd           (all indexed by SOURCE channel)
+  const float* ap1;            // ATR 1: scale  | ATR 2: K1 = A*mean(g)
+  const float* ap2;            // ATR 1: shift  | ATR 2: K2 = A*rstd*mean(g*xhat)
+  const float* ap3;            //               | ATR 2: mean
+  const void* ep_x;            // EPI 1: raw conv output the destination tensor is the (post-ReLU) gradient of
+  long ld_ep;                  //        its pixel stride (elements)
+  const unsigned char* ep_mask;//        ReLU sign bytes [pixel][NC/4], or NULL: recompute the decision from ep_x when GF_EPI_RELU
+  const float* ep_mean;        //        per DESTINATION channel
+  const float* ep_rstd;
+  const float* ep_scale;
+  const float* ep_shift;
+  float* ep_part;              //        [chunks][2][NC] partial sums (sum g, sum g*xhat), one chunk per 128-row tile
+  int ep_chunk0;               //        first chunk of this launch (parity classes of a strided data gradient)
+};
+
 #define GF_RELU 1
 #define GF_ACCUM 2
 #define GF_VEC_EPI 4   // set by the host when the float4 epilogue is legal (alignment, NC % 4 == 0)
 #define GF_STATS 8     // emit BatchNorm chunk partials from the vector epilogue
+#define GF_EPI_RELU 16 // EPI 1 without sign bytes: the BatchNorm whose backward is reduced was followed by a ReLU

@@ -20,6 +20,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (e__ != hipSuccess) return (int)e__;      \
   } while (0)
 
+// BatchNorm forms shared by every kernel that applies them, so that the ReLU decision recomputed in backward is bit-identical
+// to the one taken in forward (one fused multiply-add on the mean-subtracted value, everywhere).
+__device__ __forceinline__ float edrl_bn_pre(float x, float mean, float scale, float shift) {
+  return __builtin_fmaf(x - mean, scale, shift);
+}
+__device__ __forceinline__ float edrl_bn_relu(float x, float mean, float scale, float shift) {
+  return fmaxf(edrl_bn_pre(x, mean, scale, shift), 0.f);
+}
+// d_raw = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) = A*g - K1 - K2*(x - mean)
+__device__ __forceinline__ float edrl_bn_bwd_dx(float g, float x, float A, float K1, float K2, float mean) {
+  return __builtin_fmaf(-K2, x - mean, __builtin_fmaf(A, g, -K1));
+}
+
 static inline int edrl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware bijective block remap (8 XCDs, blocks are dealt round-robin):

@@ -103,6 +103,66 @@ def _bn_bwd(dout, mask, raw, mean, rstd, gamma, want_dres):
     return d_raw, dgamma, dbeta, dres
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Fused-BatchNorm blocks (EDRL_FUSE_BN=1, default).  Inside a residual block the BatchNorm passes ride on the convolutions:
+#   forward   conv_k+1 reads the RAW output of conv_k and forms relu(bn_k(.)) in its operand load (ops.conv2d_fwd_bnin_stats);
+#             only the block output relu(bn_last(c_last) + identity) is materialised (edrl_bn_apply_res_f32, which also
+#             normalises the raw downsample branch in place of a stored copy);
+#   backward  each data-gradient kernel masks its result with the ReLU decision of the BatchNorm below (recomputed from the
+#             raw tensor, or the sign bytes of the block output) and emits that BatchNorm's partial sums from its epilogue;
+#             d_raw = A*g - K1 - K2*(x-mean) is formed in the operand loads of the next dgrad / wgrad kernels.
+# Per conv->BN unit this removes bn_apply (fwd), colstat + bn_bwd_apply (bwd), the activated copy and the d_raw tensor.
+# A block whose layer geometries lack the fused fast paths (edrl_conv2d_fused_ok_f32: tiny / odd maps) keeps the separate
+# passes; the gradient handed from block to block is ("plain", dout) or ("masked", g, part, chunks, planes).
+_FUSE_BN = os.environ.get("EDRL_FUSE_BN", "1") != "0"
+
+
+def _fcoef_from_partials(part, chunks, M, C, bn):
+    """conv-epilogue chunk partials -> fcoef [4][C] = {mean, rstd, scale, shift}; running statistics updated in place."""
+    dev = part.device
+    fc = torch.empty((4, C), device=dev, dtype=torch.float32)
+    gbytes = L.query("edrl_bn_finalize_group_ws_bytes", chunks, C)
+    gws = torch.empty(max(gbytes // 8, 1), device=dev, dtype=torch.float64)
+    L.call("edrl_bn_finalize_partials_f32", P(part), chunks, 128, M, C, P(bn["weight"]), P(bn["bias"]),
+           P(bn["running_mean"]), P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(fc[0]), P(fc[1]),
+           P(fc[2]), P(fc[3]), P(gws), gbytes)
+    return fc
+
+
+def _bcoef_from_partials(part, chunks, planes, M, gamma, fcoef):
+    """BatchNorm-backward partial sums -> (bcoef [4][C], dgamma, dbeta)."""
+    C = fcoef.shape[1]
+    dev = part.device
+    bc = torch.empty((4, C), device=dev, dtype=torch.float32)
+    dgamma = torch.empty(C, device=dev, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    gbytes = L.query("edrl_bn_bwd_group_ws_bytes", chunks, C)
+    gws = torch.empty(max(gbytes // 8, 1), device=dev, dtype=torch.float64)
+    L.call("edrl_bn_bwd_finalize_partials_f32", P(part), chunks, planes, M, C, P(gamma), P(fcoef), P(dgamma), P(dbeta), P(bc),
+           P(gws), gbytes)
+    return bc, dgamma, dbeta
+
+
+def _bn_bwd_reduce(dout, mask, raw, fcoef, want_g):
+    """Standalone first half of a BatchNorm(+ReLU) backward: -> (g = dout*mask | dout itself, part, chunks, planes=3)."""
+    C = raw.shape[-1]
+    M = raw.numel() // C
+    g = torch.empty_like(raw) if want_g else None
+    ws, nbytes = _bn_ws(M, C, raw.device)
+    L.call("edrl_bn_bwd_reduce_f32", P(dout), P(mask), P(raw), P(fcoef), P(g), P(ws), nbytes, M, C)
+    return (g if want_g else dout), ws, (M + 1023) // 1024, 3
+
+
+def _dbg_act(raw, fc):
+    """(tests only) the activation a fused consumer forms on the fly: relu(fma(x-mean, scale, shift))."""
+    return torch.relu(torch.addcmul(fc[3], raw - fc[0], fc[2]))
+
+
+def _dbg_draw(g, raw, bc):
+    """(tests only) d_raw = A*g - K1 - K2*(x-mean) as the fused consumers form it."""
+    return bc[0] * g - bc[1] - bc[2] * (raw - bc[3])
+
+
 class _TrunkFn(torch.autograd.Function):
     """x NHWC [N,H,W,Cin] -> feature map NHWC [N,h,w,C].  params: flat tensor list (see ResNetTrunk)."""
 
@@ -113,15 +173,56 @@ class _TrunkFn(torch.autograd.Function):
         bnd = T.bn_dict
         saved = {}
         x = ops._chk(x, "encoder input")
+        cap = T._capture     # None, or a dict filled with every layer's operands/results (tests/test_gpu_layerwise.py)
+        T._wt_cache = {}     # permuted weights are shared by the backward passes that follow this forward
 
         def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
-            return _conv_bn_fwd(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
+            r = _conv_bn_fwd(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
+            if cap is not None:
+                cap[conv_name] = dict(bn=bn_name, inp=inp, stride=stride, pad=pad, relu=relu, residual=residual, raw=r[0],
+                                      out=r[1], mean=r[2], rstd=r[3], mask=r[4])
+            return r
+
+        def cf(conv_name, bn_name, inp, in_fc, stride, pad):
+            """fused unit: conv over `inp` (a raw tensor + its fcoef, or an activated tensor when in_fc is None)."""
+            w = p[conv_name + ".weight"]
+            if in_fc is None:
+                raw, part, chunks = ops.conv2d_fwd_stats(inp, w, None, stride, pad)
+            else:
+                raw, part, chunks = ops.conv2d_fwd_bnin_stats(inp, in_fc, w, stride, pad)
+            C = raw.shape[-1]
+            fc = _fcoef_from_partials(part, chunks, raw.numel() // C, C, bnd(bn_name, p))
+            if cap is not None:
+                cap[conv_name] = dict(bn=bn_name, inp=inp if in_fc is None else _dbg_act(inp, in_fc), stride=stride, pad=pad,
+                                      relu=True, residual=None, raw=raw, out=_dbg_act(raw, fc), mean=fc[0], rstd=fc[1],
+                                      mask=None, fused=True)
+            return raw, fc
+
+        def block_fused_ok(blk, cur):
+            if not _FUSE_BN:
+                return False
+            N, H, W, Ci = cur.shape
+            s = blk["stride"]
+            pl = p[blk["name"] + ".conv1.weight"].shape[0]
+            Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+            if T.kind == "bottleneck":
+                geo = [(H, W, Ci, pl, 1, 1, 0), (H, W, pl, pl, 3, s, 1), (Ho, Wo, pl, 4 * pl, 1, 1, 0)]
+                co = 4 * pl
+            else:
+                geo = [(H, W, Ci, pl, 3, s, 1), (Ho, Wo, pl, pl, 3, 1, 1)]
+                co = pl
+            if blk["downsample"]:
+                geo.append((H, W, Ci, co, 1, s, 0))
+            return all(ops.conv_fused_ok(N, h, w, ci, c_o, k, st, pd) for h, w, ci, c_o, k, st, pd in geo)
 
         # stem: as a 4x4 conv over the space-to-depth image when no input gradient is wanted (ops.stem_conv_fwd)
         folded = False
         if _STEM_S2D and not x.requires_grad:
             raw, x_keep, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
             a0, m0, r0, k0 = _bn_fwd(raw, bnd("bn1", p), True)
+            if cap is not None:
+                cap["conv1"] = dict(bn="bn1", inp=x, stride=2, pad=3, relu=True, residual=None, raw=raw, out=a0, mean=m0,
+                                    rstd=r0, mask=k0)
         else:
             raw, a0, m0, r0, k0 = cb("conv1", "bn1", x, 2, 3, True)
             x_keep = x
@@ -131,10 +232,43 @@ class _TrunkFn(torch.autograd.Function):
         idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
         L.call("edrl_maxpool3x3s2_fwd_f32", P(a0), P(p0), P(idx), N, H, W, C)
         saved["stem"] = (x_keep, folded, raw, a0.shape, m0, r0, k0, idx)
+        if cap is not None:
+            cap["maxpool"] = dict(inp=a0, out=p0, idx=idx)
         cur = p0
         for blk in T.blocks:
             pre, s = blk["name"], blk["stride"]
             rec = {"x": cur}
+            if block_fused_ok(blk, cur):
+                rec["fused"] = True
+                cd = fd = None
+                if blk["downsample"]:
+                    cd, fd = cf(pre + ".downsample.0", pre + ".downsample.1", cur, None, s, 0)
+                    rec.update(cd=cd, fd=fd)
+                if T.kind == "bottleneck":
+                    c1, f1 = cf(pre + ".conv1", pre + ".bn1", cur, None, 1, 0)
+                    c2, f2 = cf(pre + ".conv2", pre + ".bn2", c1, f1, s, 1)
+                    cl, fl = cf(pre + ".conv3", pre + ".bn3", c2, f2, 1, 0)
+                    rec.update(c1=c1, f1=f1, c2=c2, f2=f2, c3=cl, f3=fl)
+                    last = pre + ".conv3"
+                else:
+                    c1, f1 = cf(pre + ".conv1", pre + ".bn1", cur, None, s, 1)
+                    cl, fl = cf(pre + ".conv2", pre + ".bn2", c1, f1, 1, 1)
+                    rec.update(c1=c1, f1=f1, c2=cl, f2=fl)
+                    last = pre + ".conv2"
+                Cl = cl.shape[-1]
+                Ml = cl.numel() // Cl
+                out = torch.empty_like(cl)
+                kl = torch.empty((Ml, Cl // 4), device=cl.device, dtype=torch.uint8)
+                L.call("edrl_bn_apply_res_f32", P(cl), P(fl), P(cd if cd is not None else cur), P(fd), P(out), P(kl), Ml, Cl, 1)
+                rec.update(kl=kl)
+                if cap is not None:
+                    cap[last].update(out=out, mask=kl, residual=(cur if cd is None else
+                                                                 torch.addcmul(fd[3], cd - fd[0], fd[2])))
+                    if cd is not None:
+                        cap[pre + ".downsample.0"].update(relu=False, out=torch.addcmul(fd[3], cd - fd[0], fd[2]))
+                saved[pre] = rec
+                cur = out
+                continue
             if blk["downsample"]:
                 cd, idn, md, rd, _ = cb(pre + ".downsample.0", pre + ".downsample.1", cur, s, 0, False)
                 rec.update(cd=cd, sd=(md, rd))
@@ -156,6 +290,7 @@ class _TrunkFn(torch.autograd.Function):
         ctx.saved = saved
         ctx.params = p
         ctx.needs_x = x.requires_grad
+        ctx.cap = cap
         T.bump_batches_tracked()
         return cur
 
@@ -164,7 +299,16 @@ class _TrunkFn(torch.autograd.Function):
         T, saved, p = ctx.trunk, ctx.saved, ctx.params
         ctx.saved = None
         grads = {}
-        dcur = dout.contiguous()
+        cap = ctx.cap
+        wt_cache = T._wt_cache
+
+        def wt_of(name):
+            """[Ci,KH,KW,Co] copy of a conv weight for the data gradient, shared by the two views' backward passes."""
+            key = (name, torch.cuda.current_stream().cuda_stream)     # (two-stream view overlap: one copy per stream)
+            t = wt_cache.get(key)
+            if t is None:
+                t = wt_cache[key] = ops.permute_weight(p[name + ".weight"])
+            return t
 
         # Weight gradients are off the critical chain (dgrad -> BN backward -> dgrad ...): they are issued on a side
         # stream so the MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm-backward kernels of the main stream.
@@ -175,18 +319,22 @@ class _TrunkFn(torch.autograd.Function):
             w = p[name + ".weight"]
             if side is None:
                 grads[name + ".weight"] = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+                if cap is not None:
+                    cap[name].update(d_raw=dy, dW=grads[name + ".weight"],
+                                     dx_before=dx_out.clone() if (accumulate and dx_out is not None) else None)
                 if not need_dx:
                     return None
-                return ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
-                                        accumulate=accumulate)
+                dx = ops.conv2d_dgrad(dy, wt_of(name), tuple(inp.shape), stride, pad, out=dx_out, accumulate=accumulate)
+                if cap is not None:
+                    cap[name]["dx_after"] = dx.clone()
+                return dx
             # Side-stream schedule: [join the previous wgrad] -> dgrad (alone on the GPU: its timing stays clean) ->
             # wgrad on the side stream, which then runs beside the NEXT layer's BatchNorm-backward kernels (MFMA-bound
             # beside HBM-bound) until the next dgrad joins it.
             main.wait_stream(side)
             dx = None
             if need_dx:
-                dx = ops.conv2d_dgrad(dy, ops.permute_weight(w), tuple(inp.shape), stride, pad, out=dx_out,
-                                      accumulate=accumulate)
+                dx = ops.conv2d_dgrad(dy, wt_of(name), tuple(inp.shape), stride, pad, out=dx_out, accumulate=accumulate)
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):
                 dw = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
@@ -198,12 +346,112 @@ class _TrunkFn(torch.autograd.Function):
             d_raw, dg, db, dres = _bn_bwd(dy, mask, raw, st[0], st[1], p[name + ".weight"], want_dres)
             grads[name + ".weight"] = dg
             grads[name + ".bias"] = db
+            if cap is not None:
+                cap["bwd:" + name] = dict(dout=dy.clone(), dgamma=dg, dbeta=db, d_raw=d_raw,
+                                          dres=dres.clone() if dres is not None else None)
             return d_raw, dres
 
-        for blk in reversed(T.blocks):
+        # ---- fused units
+        def fin_bwd(bn_name, part, chunks, planes, raw, fc):
+            C = raw.shape[-1]
+            bc, dg, db = _bcoef_from_partials(part, chunks, planes, raw.numel() // C, p[bn_name + ".weight"], fc)
+            grads[bn_name + ".weight"] = dg
+            grads[bn_name + ".bias"] = db
+            return bc
+
+        def fwgrad(name, g, raw, bc, xin, x_fc, stride, pad):
+            w = p[name + ".weight"]
+            grads[name + ".weight"] = ops.conv2d_wgrad_bn(g, raw, bc, xin, x_fc, tuple(w.shape), stride, pad)
+
+        def fcap(conv_name, bn_name, g, raw, bc, dres=None):
+            if cap is not None:
+                dr = _dbg_draw(g, raw, bc)
+                cap["bwd:" + bn_name] = dict(dout=g.clone(), dgamma=grads[bn_name + ".weight"], dbeta=grads[bn_name + ".bias"],
+                                             d_raw=dr, dres=dres, masked=True)
+                cap[conv_name].update(d_raw=dr, dW=grads[conv_name + ".weight"])
+
+        def fdgrad(name, g, raw, bc, x_shape, stride, pad, out=None, accumulate=False, ep=None, ep_keep=None):
+            before = out.clone() if (cap is not None and accumulate) else None
+            r = ops.conv2d_dgrad_bn(g, raw, bc, wt_of(name), tuple(x_shape), stride, pad, out=out, accumulate=accumulate, ep=ep)
+            if cap is not None:
+                cap[name].update(dx_before=before, dx_after=(r if ep is None else r[0]).clone(),
+                                 dx_keep=ep_keep() if (ep is not None and ep_keep is not None) else None)
+            return r
+
+        def lower_ep(bi):
+            """Epilogue operands for the BatchNorm(+ReLU) that produced the input of block bi (the block below's last unit),
+            when that block is fused: (raw, sign bytes, fcoef, relu)."""
+            if bi == 0:
+                return None, None
+            lo = saved[T.blocks[bi - 1]["name"]]
+            if not lo.get("fused"):
+                return None, None
+            raw_lo, fc_lo = (lo["c3"], lo["f3"]) if T.kind == "bottleneck" else (lo["c2"], lo["f2"])
+            kl = lo["kl"]
+            keep = lambda: _mask_to_bool(kl, raw_lo.shape)
+            return (raw_lo, kl, fc_lo, True), keep
+
+        def recompute_keep(raw, fc):     # (tests) the pre-activation whose sign the epilogue re-derives
+            return lambda: torch.addcmul(fc[3], raw - fc[0], fc[2])
+
+        grad_in = ("plain", dout.contiguous())
+        for bi in range(len(T.blocks) - 1, -1, -1):
+            blk = T.blocks[bi]
             pre, s = blk["name"], blk["stride"]
-            rec = saved.pop(pre)
+            ep_lo, keep_lo = lower_ep(bi)
+            rec = saved[pre]
             xin = rec["x"]
+            if rec.get("fused"):
+                bott = T.kind == "bottleneck"
+                last, last_bn = (pre + ".conv3", pre + ".bn3") if bott else (pre + ".conv2", pre + ".bn2")
+                cl, fl = (rec["c3"], rec["f3"]) if bott else (rec["c2"], rec["f2"])
+                if grad_in[0] == "plain":
+                    gl, part, chunks, planes = _bn_bwd_reduce(grad_in[1], rec["kl"], cl, fl, want_g=True)
+                else:
+                    _, gl, part, chunks, planes = grad_in
+                bl = fin_bwd(last_bn, part, chunks, planes, cl, fl)
+                c1, f1 = rec["c1"], rec["f1"]
+                if bott:
+                    c2, f2 = rec["c2"], rec["f2"]
+                    fwgrad(last, gl, cl, bl, c2, f2, 1, 0)
+                    fcap(last, last_bn, gl, cl, bl, dres=gl.clone() if cap is not None else None)
+                    g2, part, chunks = fdgrad(last, gl, cl, bl, c2.shape, 1, 0, ep=(c2, None, f2, True),
+                                              ep_keep=recompute_keep(c2, f2))
+                    b2 = fin_bwd(pre + ".bn2", part, chunks, 2, c2, f2)
+                    fwgrad(pre + ".conv2", g2, c2, b2, c1, f1, s, 1)
+                    fcap(pre + ".conv2", pre + ".bn2", g2, c2, b2)
+                    g1, part, chunks = fdgrad(pre + ".conv2", g2, c2, b2, c1.shape, s, 1, ep=(c1, None, f1, True),
+                                              ep_keep=recompute_keep(c1, f1))
+                    c1_stride, c1_pad = 1, 0
+                else:
+                    fwgrad(last, gl, cl, bl, c1, f1, 1, 1)
+                    fcap(last, last_bn, gl, cl, bl, dres=gl.clone() if cap is not None else None)
+                    g1, part, chunks = fdgrad(last, gl, cl, bl, c1.shape, 1, 1, ep=(c1, None, f1, True),
+                                              ep_keep=recompute_keep(c1, f1))
+                    c1_stride, c1_pad = s, 1
+                b1 = fin_bwd(pre + ".bn1", part, chunks, 2, c1, f1)
+                fwgrad(pre + ".conv1", g1, c1, b1, xin, None, c1_stride, c1_pad)
+                fcap(pre + ".conv1", pre + ".bn1", g1, c1, b1)
+                # block-input gradient: (downsample branch | identity) first, conv1's data gradient accumulated last so that
+                # its epilogue sees the complete gradient of the block below's output
+                if blk["downsample"]:
+                    cd, fd = rec["cd"], rec["fd"]
+                    _, partd, chunksd, planesd = _bn_bwd_reduce(gl, None, cd, fd, want_g=False)
+                    bd = fin_bwd(pre + ".downsample.1", partd, chunksd, planesd, cd, fd)
+                    fwgrad(pre + ".downsample.0", gl, cd, bd, xin, None, s, 0)
+                    fcap(pre + ".downsample.0", pre + ".downsample.1", gl, cd, bd)
+                    dx = fdgrad(pre + ".downsample.0", gl, cd, bd, xin.shape, s, 0)      # full cover (zero fill off-lattice)
+                else:
+                    dx = gl
+                r = fdgrad(pre + ".conv1", g1, c1, b1, xin.shape, c1_stride, c1_pad, out=dx, accumulate=True, ep=ep_lo,
+                           ep_keep=keep_lo)
+                grad_in = ("plain", r) if ep_lo is None else ("masked", r[0], r[1], r[2], 2)
+                del rec, saved[pre]
+                continue
+            # ---- separate-pass block
+            if grad_in[0] == "masked":      # (not produced: a fused block masks only for a fused block below)
+                raise RuntimeError("internal: masked gradient handed to an unfused block")
+            dcur = grad_in[1]
             if T.kind == "bottleneck":
                 d3, g = bn_bwd(pre + ".bn3", dcur, rec["kl"], rec["c3"], rec["sl"], want_dres=True)
             else:
@@ -230,21 +478,39 @@ class _TrunkFn(torch.autograd.Function):
                 dx = g
                 conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad, dx_out=dx, accumulate=True)
             del g
-            dcur = dx
-            del rec
+            if ep_lo is not None:            # the block below is fused: hand it the masked gradient + partial sums
+                lo_raw, lo_mask, lo_fc, _ = ep_lo
+                gl, part, chunks, planes = _bn_bwd_reduce(dx, lo_mask, lo_raw, lo_fc, want_g=True)
+                grad_in = ("masked", gl, part, chunks, planes)
+            else:
+                grad_in = ("plain", dx)
+            del rec, saved[pre]
+        dcur = grad_in[1]
         x, folded, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
         N, H, W, C = a0_shape
         da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.float32)
         L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
+        if cap is not None:
+            cap["maxpool"].update(dout=dcur, dinp=da0)
         draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))
         if folded:
             grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), True)
+            if cap is not None:
+                cap["conv1"].update(d_raw=draw, dW=grads["conv1.weight"], dx_before=None, dx_after=None)
             dx = None
         else:
             dx = conv_bwd("conv1", draw, x, 2, 3, need_dx=ctx.needs_x)
         if side is not None:
             main.wait_stream(side)
         return (None, dx) + tuple(grads.get(n) for n in T.param_names)
+
+
+def _mask_to_bool(mask, shape):
+    """(tests only) ReLU sign bytes [M, C/4] -> bool tensor of `shape` [..., C]"""
+    C = shape[-1]
+    m = mask.view(-1, C // 4, 1).to(torch.int32)
+    sh = torch.arange(4, dtype=torch.int32, device=mask.device).view(1, 1, 4)
+    return ((m >> sh) & 1).bool().view(shape)
 
 
 # ------------------------------------------------------------------------------------------------ bf16 trunk (C2/C4)
@@ -437,6 +703,8 @@ class ResNetTrunk(nn.Module):
                 inpl = outp
         self.out_channels = inpl
         self.param_names = [n for n, _ in self.named_parameters()]
+        self._capture = None
+        self._wt_cache = {}
 
     # parameters are registered under dotted torchvision-style names with '.' -> '__' for attribute safety
     def _reg(self, name, tensor, buffer=False):

@@ -224,6 +224,64 @@ def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False, al
     return out
 
 
+# ---- convolutions with the neighbouring BatchNorm passes folded into their operand loads / epilogues (include/edrl_hip.h:
+# fcoef [4][C] = {mean, rstd, scale, shift}, bcoef [4][C] = {A, K1, K2, mean})
+def conv_fused_ok(N, Hi, Wi, Ci, Co, KH, stride, pad):
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KH) // stride + 1
+    return bool(L.query("edrl_conv2d_fused_ok_f32", N, Hi, Wi, Ci, Ho, Wo, Co, KH, KH, stride, pad))
+
+
+def conv2d_fwd_bnin_stats(x_raw, in_fcoef, w, stride=1, pad=0):
+    """y = conv(relu(bn(x_raw; in_fcoef)), w) + the BatchNorm chunk partials of y.  -> (y, part, chunks)."""
+    N, Hi, Wi, Ci = x_raw.shape
+    Co, KH, KW, _ = w.shape
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    out = torch.empty((N, Ho, Wo, Co), device=x_raw.device, dtype=torch.float32)
+    chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
+    part = torch.empty((chunks, 3, Co), device=x_raw.device, dtype=torch.float32)
+    _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_bnin_stats_f32", P(x_raw),
+                  P(in_fcoef), P(w), P(out), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)
+    return out, part, chunks
+
+
+def conv2d_dgrad_bn(g, yraw, bcoef, wt, x_shape, stride=1, pad=0, out=None, accumulate=False, ep=None):
+    """dx (+)= conv_transpose(d_raw(g, yraw; bcoef)).  ep = (raw, mask_bytes | None, fcoef, relu) of the BatchNorm whose output
+    dx is the gradient of: dx is then masked in the epilogue and the partial sums of that BatchNorm's backward are returned.
+    -> dx  |  (dx, part [chunks][2][Ci], chunks)."""
+    N, Hi, Wi, Ci = x_shape
+    _, Ho, Wo, Co = g.shape
+    KH, KW = wt.shape[1], wt.shape[2]
+    if out is None:
+        out = torch.empty((N, Hi, Wi, Ci), device=g.device, dtype=torch.float32)
+        accumulate = False
+    part, chunks, nbytes = None, 0, 0
+    if ep is not None:
+        chunks = L.query("edrl_conv_dgrad_bn_chunks", N, Hi, Wi, stride, pad)
+        part = torch.empty((chunks, 2, Ci), device=g.device, dtype=torch.float32)
+        nbytes = part.numel() * 4
+    ep_raw, ep_mask, ep_fcoef, ep_relu = ep if ep is not None else (None, None, None, False)
+    kernels = _dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate and ep is None)
+    _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bn_f32", P(g), P(yraw), P(bcoef),
+                  P(wt), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0, P(ep_raw),
+                  P(ep_mask), P(ep_fcoef), 1 if ep_relu else 0, P(part), nbytes, kernels=kernels)
+    return out if ep is None else (out, part, chunks)
+
+
+def conv2d_wgrad_bn(g, yraw, bcoef, x, x_fcoef, w_shape, stride=1, pad=0):
+    """dw = sum_pixels d_raw(g, yraw; bcoef) (x) X with X = relu(bn(x; x_fcoef)) (x_fcoef None: x as is)."""
+    N, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = g.shape
+    KH, KW = w_shape[1], w_shape[2]
+    out = torch.empty(w_shape, device=g.device, dtype=torch.float32)
+    nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
+    ws = torch.empty(nbytes // 4, device=g.device, dtype=torch.float32)
+    _launch_timed("conv_wgrad", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_bn_f32", P(g), P(yraw), P(bcoef),
+                  P(x), P(x_fcoef), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 0)
+    return out
+
+
 def linear_fwd(x2, w, bias=None, mul=None, relu=False):
     """x2 [rows, in] (row stride allowed), w [out, in] -> [rows, out]."""
     rows, cin = x2.shape
