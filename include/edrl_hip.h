@@ -68,9 +68,10 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
 
 /* ---- Convolutions with the neighbouring BatchNorm passes folded in (encoder slots behind fusion_net.py:884-885; SURVEY.md
  * §8a rows E1-E3: conv -> BatchNorm2d(train) -> ReLU chains).  Dense NHWC fp32 tensors, 16-byte aligned.  Coefficient arrays:
- *   fcoef [4][C] = {mean, rstd, scale = gamma*rstd, shift = beta}   (rows written by edrl_bn_finalize_partials_f32)
- *   bcoef [4][C] = {A = gamma*rstd, K1 = A*mean(g), K2 = A*rstd*mean(g*xhat), mean}  (edrl_bn_bwd_finalize_partials_f32)
- * so that relu((x-mean)*scale+shift) and d_raw = A*g - K1 - K2*(x-mean) are formed inside the conv kernels' operand loads and
+ *   fcoef [5][C] = {mean, rstd, scale = gamma*rstd, shift = beta, shift2 = shift - mean*scale}   (edrl_bn_finalize_fcoef_f32)
+ *   bcoef [4][C] = {A = gamma*rstd, nK2 = -A*rstd*mean(g*xhat), C2 = -nK2*mean - A*mean(g), mean}
+ *                                                                                    (edrl_bn_bwd_finalize_partials_f32)
+ * so that relu(x*scale + shift2) and d_raw = A*g + nK2*x + C2 are formed inside the conv kernels' operand loads and
  * the activated tensors / d_raw tensors (torch: F.batch_norm + F.relu outputs and their autograd buffers) never exist.
  * edrl_conv2d_fused_ok_f32 says whether a layer geometry has these paths (1) or must use the separate passes (0). */
 int edrl_conv2d_fused_ok_f32(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad);
@@ -80,7 +81,7 @@ int edrl_conv2d_nhwc_fwd_bnin_stats_f32(const float* x, const float* in_fcoef, c
                                         int KW, int stride, int pad, hipStream_t stream);
 /* dx [+]= conv_transpose(d_raw(g, yraw; bcoef), w).  With ep_raw != NULL, dx is the gradient of relu?(bn(ep_raw)) of the layer
  * below: the epilogue masks it (ep_mask sign bytes [pixel][Ci/4], or recomputed from ep_raw / ep_fcoef when ep_mask == NULL and
- * ep_relu), stores the masked gradient and writes (sum g, sum g*xhat) per 128-row tile to
+ * ep_relu), stores the masked gradient and writes (sum g, sum g*x) per 128-row tile to
  * ep_part [edrl_conv_dgrad_bn_chunks(N,Hi,Wi,stride,pad)][2][Ci].  flags: 2 = accumulate into dx before masking. */
 long edrl_conv_dgrad_bn_chunks(int N, int Hi, int Wi, int stride, int pad);
 int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g, const float* yraw, const float* bcoef, const float* wt, float* dx, int N,
@@ -148,13 +149,19 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* re
                     int accumulate, float* dx, float* dres, int dres_accum, long M, int C, long ld, float* workspace,
                     size_t workspace_bytes, hipStream_t stream);
 
+/* edrl_bn_finalize_partials_f32 with the result as ONE array fcoef [5][C] = {mean, rstd, scale, shift, shift2 = shift -
+ * mean*scale} (the form the fused conv kernels take: relu(x*scale + shift2) is one packed FMA + max per element). */
+int edrl_bn_finalize_fcoef_f32(const float* part, long nchunks, int rows_per_chunk, long M, int C, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* fcoef, double* group_ws, size_t group_ws_bytes, hipStream_t stream);
 /* BatchNorm apply whose residual operand may be a raw conv output with its own BatchNorm (downsample branch; res_fcoef NULL:
  * plain residual): out = act(bn(x; fcoef) + bn(residual; res_fcoef)), ReLU sign bytes -> relu_mask (optional). */
 int edrl_bn_apply_res_f32(const float* x, const float* fcoef, const float* residual, const float* res_fcoef, float* out,
                           unsigned char* relu_mask, long M, int C, int relu, hipStream_t stream);
 /* BatchNorm(+ReLU) backward split for the fused conv kernels.  _reduce: g = dout * relu-mask (optional) -> g_out (optional),
  * partial sums (sum g, sum g*xhat) -> part [ceil(M/1024)][3][C] (edrl_bn_workspace_bytes).  _finalize: partial sums with
- * `planes` planes per chunk (3 from _reduce, 2 from edrl_conv2d_nhwc_dgrad_bn_f32) -> dgamma, dbeta, bcoef [4][C]. */
+ * `planes` planes per chunk (3 from _reduce; 2 from edrl_conv2d_nhwc_dgrad_bn_f32, whose second plane is sum g*x and is
+ * converted here in fp64) -> dgamma, dbeta, bcoef [4][C]. */
 int edrl_bn_bwd_reduce_f32(const float* dout, const unsigned char* relu_mask, const float* x, const float* fcoef, float* g_out,
                            float* part, size_t part_bytes, long M, int C, hipStream_t stream);
 size_t edrl_bn_bwd_group_ws_bytes(long nchunks, int C);

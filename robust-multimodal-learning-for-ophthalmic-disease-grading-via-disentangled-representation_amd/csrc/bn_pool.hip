@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ running_var, float momentum,
                                                           float eps, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+                                                          float* __restrict__ shift, float* __restrict__ shift2 = nullptr) {
   __shared__ double sh[256];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
   // pass 1: mean = sum_c (n_c K_c + S1_c) / M
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const float sc = gm * rs;
     scale[c] = sc;
     shift[c] = bt;  // applied as (x - mean)*scale + shift: subtract first, no cancellation
+    if (shift2) shift2[c] = (float)((double)bt - mu * (double)sc);   // single-FMA form x*scale + shift2 of the fused conv loads
     if (running_mean) {
       const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_finalize_groups_kernel(const double* _
                                                                 float* __restrict__ running_var, float momentum,
                                                                 float eps, float* __restrict__ mean_out,
                                                                 float* __restrict__ rstd_out, float* __restrict__ scale,
-                                                                float* __restrict__ shift) {
+                                                                float* __restrict__ shift, float* __restrict__ shift2 = nullptr) {
   // 16 channels x 16 lanes per workgroup: a lane walks every 16th group (several hundred groups for the 56x56 layers:
   // one thread per channel was a ~50 us chain of dependent loads on the critical path of every conv+BN pair)
   __shared__ double sh[256];
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256) void bn_finalize_groups_kernel(const double* _
   const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
   scale[c] = gm * rs;
   shift[c] = bt;
+  if (shift2) shift2[c] = (float)((double)bt - mu * (double)(gm * rs));
   if (running_mean) {
     const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
@@ -316,8 +318,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 // ---- BatchNorm backward finalize from per-tile partial sums part[chunk][planes][C] (plane 0 = sum g, plane 1 = sum g*xhat;
 // the fused data-gradient epilogue emits planes = 2 with one chunk per 128 rows, colstat_kernel<1> planes = 3 per 1024 rows).
-// -> dgamma, dbeta and bcoef [4][C] = {A = gamma*rstd, K1 = A*mean(g), K2 = A*rstd*mean(g*xhat), mean}: the coefficients the
-// consumers (conv_gemm.hip ATR 2 / DYT 2) need to form d_raw = A*g - K1 - K2*(x - mean) on the fly.
+// With planes = 2 plane 1 is sum g*x (raw x; converted to sum g*xhat = rstd*(sum g*x - mean*sum g) here, in fp64).
+// -> dgamma, dbeta and bcoef [4][C] = {A = gamma*rstd, nK2 = -A*rstd*mean(g*xhat), C2 = -nK2*mean - A*mean(g), mean}: the
+// coefficients from which the consumers (conv_gemm.hip ATR 2 / DYT 2) form d_raw = A*g + nK2*x + C2 with two packed FMAs.
 __global__ __launch_bounds__(256) void bn_bwd_group_kernel(const float* __restrict__ part, int nchunks, int planes, int C,
                                                            double* __restrict__ gout) {
   __shared__ double sh[256];
@@ -358,15 +361,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_coef_kernel(const float* 
       }
     }
   }
-  const double s0 = fin_lane_sum(a0, sh), s1 = fin_lane_sum(a1, sh);
+  const double s0 = fin_lane_sum(a0, sh);
+  double s1 = fin_lane_sum(a1, sh);
   if (q != 0 || c >= C) return;
+  const double rs = (double)rstd[c], mu = (double)mean[c];
+  if (planes == 2) s1 = rs * (s1 - mu * s0);      // the conv epilogue accumulates sum g*x: -> sum g*xhat
   if (dbeta) dbeta[c] = (float)s0;
   if (dgamma) dgamma[c] = (float)s1;
-  const float rs = rstd[c];
-  const float A = (gamma ? gamma[c] : 1.f) * rs;
-  bcoef[c] = A;
-  bcoef[C + c] = A * (float)(s0 / (double)M);
-  bcoef[2 * (long)C + c] = A * rs * (float)(s1 / (double)M);
+  const double A = (double)(gamma ? gamma[c] : 1.f) * rs;
+  const double nK2 = -A * rs * (s1 / (double)M);
+  bcoef[c] = (float)A;
+  bcoef[C + c] = (float)nK2;
+  bcoef[2 * (long)C + c] = (float)(-nK2 * mu - A * (s0 / (double)M));
   bcoef[3 * (long)C + c] = mean[c];
 }
 
@@ -898,6 +904,32 @@ int edrl_bn_finalize_partials_f32(const float* part, long nchunks, int rows_per_
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, part, (int)nchunks, C, M,
                      rows_per_chunk, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale,
                      shift);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Same reduction, output as ONE coefficient array fcoef [5][C] = {mean, rstd, scale, shift, shift2 = shift - mean*scale}
+// (the layout the fused conv kernels and edrl_bn_apply_res_f32 / edrl_bn_bwd_reduce_f32 take).
+int edrl_bn_finalize_fcoef_f32(const float* part, long nchunks, int rows_per_chunk, long M, int C, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* fcoef, double* group_ws, size_t group_ws_bytes, hipStream_t st) {
+  if (M <= 0 || C <= 0 || nchunks <= 0 || nchunks > 0x7fffffffL || rows_per_chunk <= 0 || !fcoef ||
+      nchunks != (M + rows_per_chunk - 1) / rows_per_chunk)
+    return EDRL_EINVAL;
+  float *mean = fcoef, *rstd = fcoef + C, *scale = fcoef + 2 * (long)C, *shift = fcoef + 3 * (long)C, *shift2 = fcoef + 4 * (long)C;
+  if (group_ws && nchunks > 2 * FIN_GROUP) {
+    if (group_ws_bytes < edrl_bn_finalize_group_ws_bytes(nchunks, C)) return EDRL_ENOSPC;
+    const int G = (int)((nchunks + FIN_GROUP - 1) / FIN_GROUP);
+    hipLaunchKernelGGL(bn_group_kernel, dim3(edrl_cdiv(C, FIN_CH), G), dim3(256), 0, st, part, (int)nchunks, C, M,
+                       rows_per_chunk, group_ws);
+    EDRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, group_ws, G, C, M, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, rstd, scale, shift, shift2);
+    EDRL_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, part, (int)nchunks, C, M,
+                     rows_per_chunk, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift, shift2);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

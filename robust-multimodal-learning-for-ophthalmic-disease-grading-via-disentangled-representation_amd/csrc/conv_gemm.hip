@@ -252,7 +252,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //   EPI 1: (data gradient) the tile just computed is the gradient of a BatchNorm+ReLU output: the epilogue masks it with
 //          the ReLU decision (sign bytes, or recomputed from the raw tensor), stores the masked gradient and emits the
 //          per-tile partial sums (sum g, sum g*xhat) of that BatchNorm's backward -- no separate reduction pass.
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0>
+// MASK (ATR != 0): the geometry has padding taps / masked rows that must read as exactly 0 AFTER the transform (false for
+// 1x1 / pad-0 layers, whose only invalid rows are rows >= M of the last tile: those are never stored).
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherFuse F) {
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   // ---- BUF state: byte offsets into the two descriptors; >= 2 GiB = masked (stays masked under the per-tile adds)
   constexpr unsigned OOB = 0x80000000u;
   unsigned aoff[A_LD], boff[B_LD], wrow4[B_LD];
-  __amdgpu_buffer_rsrc_t rs_a, rs_b, rs_a2;
+  __amdgpu_buffer_rsrc_t rs_a, rs_b, rs_a2, rs_p;
   int n_first = 0;
   int cb = 0;          // uniform part of c (c = cb + k4 while FAST)
   if constexpr (BUF) {
@@ -326,6 +328,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, (int)((long)g.NC * g.Kfull * 4), 0x00020000);
     if constexpr (ATR == 2)
       rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)F.src2 + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
+    if constexpr (ATR != 0)
+      rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)F.acoef, 0, 5 * g.SC * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int n = n0 + r0 + RPP * i;
@@ -391,14 +395,14 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 
   f32x4 a_st[A_LD], b_st[B_LD];
   f32x4 a_st2[ATR == 2 ? A_LD : 1];      // ATR 2: the raw conv output paired with the gradient in a_st
-  f32x4 tp0, tp1, tp2, tp3;              // per-channel transform parameters of the staged K tile (channels cb+k4 .. +3)
+  f32x4 tp0, tp1, tp2;                   // per-channel transform parameters of the staged K tile (channels cb+k4 .. +3)
   bool a_ok[A_LD], b_ok[B_LD];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_piece = [&](int i) {
     if constexpr (BUF) {
       a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)aoff[i], 0, 0));
       if constexpr (ATR == 2) a_st2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, (int)aoff[i], 0, 0));
-      if constexpr (ATR != 0) a_ok[i] = (int)aoff[i] >= 0;   // masked rows / padding taps / past-the-end tiles: offset >= 2 GiB
+      if constexpr (ATR != 0 && MASK) a_ok[i] = (int)aoff[i] >= 0;   // masked rows / padding taps / past-the-end tiles: offset >= 2 GiB
       if (i < B_LD) b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)boff[i], 0, 0));
       return;
     }
@@ -442,26 +446,37 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   // cycles ahead of their use in store_tile) so that they are not live across the whole chain (VGPR budget at 3 per CU).
   auto load_params = [&]() {
     if constexpr (ATR != 0) {
-      const int c = cb + k4;             // < SC always (cb < SC, SC % BKT == 0)
-      tp0 = *reinterpret_cast<const f32x4*>(F.ap0 + c);
-      tp1 = *reinterpret_cast<const f32x4*>(F.ap1 + c);
-      tp2 = *reinterpret_cast<const f32x4*>(F.ap2 + c);
-      if constexpr (ATR == 2) tp3 = *reinterpret_cast<const f32x4*>(F.ap3 + c);
+      const int po = (cb + k4) * 4;      // channels cb+k4 .. +3 (< SC always: cb < SC, SC % BKT == 0); rows via the scalar offset
+      if constexpr (ATR == 1) {          // tp0 = scale (row 2), tp1 = shift2 (row 4)
+        tp0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, 2 * g.SC * 4, 0));
+        tp1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, 4 * g.SC * 4, 0));
+      } else {                           // tp0 = A (row 0), tp1 = nK2 (row 1), tp2 = C2 (row 2)
+        tp0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, 0, 0));
+        tp1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, g.SC * 4, 0));
+        tp2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, 2 * g.SC * 4, 0));
+      }
     }
+  };
+  // The operand transform runs on the staged registers, one 4-channel piece at a time (two packed FMAs [+ max]); in the K loop
+  // the pieces are issued behind the last MFMAs of the running tile.
+  auto transform_piece = [&](int i) {     // i compile-time after unrolling
+    f32x4 v;
+    if constexpr (ATR == 1) v = edrl_bn_relu2(a_st[i], tp0, tp1);
+    else if constexpr (ATR == 2) v = edrl_bn_bwd_dx2(a_st[i], a_st2[i], tp0, tp1, tp2);
+    else v = a_st[i];
+    if constexpr (ATR != 0 && MASK) v = a_ok[i] ? v : zero4;
+    a_st[i] = v;
+  };
+  auto transform_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) transform_piece(i);
   };
   auto store_tile = [&](int buf) {
     float* a = As + buf * BM * LDKT;
     float* b = Bs + buf * BN * LDKT;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      f32x4 v = (!FAST || BUF || a_ok[i]) ? a_st[i] : zero4;
-      if constexpr (ATR == 1) {          // tp0 = mean, tp1 = scale, tp2 = shift
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a_ok[i] ? edrl_bn_relu(v[e], tp0[e], tp1[e], tp2[e]) : 0.f;
-      } else if constexpr (ATR == 2) {   // tp0 = A, tp1 = K1, tp2 = K2, tp3 = mean
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a_ok[i] ? edrl_bn_bwd_dx(v[e], a_st2[i][e], tp0[e], tp1[e], tp2[e], tp3[e]) : 0.f;
-      }
+      const f32x4 v = (!FAST || BUF || a_ok[i]) ? a_st[i] : zero4;
       *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * LDKT + k4) = v;
     }
 #pragma unroll
@@ -481,6 +496,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) load_piece(i);
   load_params();
+  transform_tile();
   store_tile(0);
   __syncthreads();
 
@@ -496,6 +512,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     if (FAST) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) load_piece(i);
+      if constexpr (ATR == 1) load_params();       // (ATR 2: fetched before the last chunk, VGPR budget)
       __builtin_amdgcn_sched_barrier(0);
     }
     // fragment registers are double buffered: chunk kc+1's LDS reads are issued ahead of chunk kc's 16 MFMAs
@@ -514,8 +531,27 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
         for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDKT + (kc + 1) * 8);
       }
       if (!FAST) load_piece(kc);
-      if constexpr (ATR != 0) {
+      if constexpr (ATR == 2) {
         if (kc == BKT / 8 - 1) { __builtin_amdgcn_sched_barrier(0); load_params(); __builtin_amdgcn_sched_barrier(0); }
+      }
+      if constexpr (ATR != 0) {
+        if (kc == BKT / 8 - 1) {
+          // last chunk: the operand transform of the NEXT tile is issued element by element behind the MFMAs of the
+          // chunk's second half (each slice pinned behind its MFMA), so its VALU instructions execute in the matrix
+          // pipe's shadow instead of between the end of the chain and the workgroup barrier.
+          constexpr int NM = 4 * TM * TN;
+#pragma unroll
+          for (int q = 0; q < NM; ++q) {
+            const int s = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+            if (q >= NM - A_LD) {          // one piece behind each of the last A_LD MFMAs
+              __builtin_amdgcn_sched_barrier(0);
+              transform_piece(q - (NM - A_LD));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          continue;
+        }
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -546,15 +582,11 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const bool stats = EPI == 0 && (g.flags & GF_STATS) != 0;
     f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
     // EPI 1: BatchNorm(+ReLU) backward of the tensor this tile is the gradient of (channels n .. n+3 of this lane)
-    f32x4 e_mean = zero4, e_rstd = zero4, e_scale = zero4, e_shift = zero4;
+    f32x4 e_scale = zero4, e_shift2 = zero4;
     if constexpr (EPI == 1) {
-      if (n < g.NC) {
-        e_mean = *reinterpret_cast<const f32x4*>(F.ep_mean + n);
-        e_rstd = *reinterpret_cast<const f32x4*>(F.ep_rstd + n);
-        if (!F.ep_mask) {
-          e_scale = *reinterpret_cast<const f32x4*>(F.ep_scale + n);
-          e_shift = *reinterpret_cast<const f32x4*>(F.ep_shift + n);
-        }
+      if (n < g.NC && !F.ep_mask) {
+        e_scale = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + n);
+        e_shift2 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + n);
       }
     }
 #pragma unroll
@@ -599,11 +631,12 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (mb >> e) & 1 ? v[e] : 0.f;
             } else if (g.flags & GF_EPI_RELU) {
+              const f32x4 pre = edrl_bn_pre2(xr, e_scale, e_shift2);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = edrl_bn_pre(xr[e], e_mean[e], e_scale[e], e_shift[e]) > 0.f ? v[e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = pre[e] > 0.f ? v[e] : 0.f;
             }
-            st0 += v;
-            st1 += v * ((xr - e_mean) * e_rstd);
+            st0 += v;                                    // sum g
+            st1 = __builtin_elementwise_fma(v, xr, st1); // sum g*x  (-> sum g*xhat in the fp64 finalize)
           }
           *reinterpret_cast<f32x4*>(p) = v;
         }
@@ -611,7 +644,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // staging reads done before the next pass overwrites them
     }
     if constexpr (EPI == 1) {
-      // (sum g, sum g*xhat) of the tile's valid rows -> F.ep_part[chunk0 + tile_m][2][NC]
+      // (sum g, sum g*x) of the tile's valid rows -> F.ep_part[chunk0 + tile_m][2][NC]
 #pragma unroll
       for (int o = 32; o >= C4; o >>= 1) {
 #pragma unroll
@@ -703,7 +736,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   }
 }
 
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0>
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
                             const float* mul, const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
@@ -711,7 +744,7 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI>;
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI, MASK>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -732,7 +765,9 @@ static bool gather_fused_ok(const float* src, const float* wm, const float* dst,
          (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) && (long)g.NC * g.Kfull * 4 < (1L << 31) &&
          g.M < (1L << 31);
 }
-#define FUSED_OCC 3
+// workgroups per CU: the forward operand transform fits the 128-VGPR budget of 4 per CU, the data-gradient variants (second
+// operand tensor + epilogue reduction) need the 168 of 3 per CU
+#define FUSED_OCC (ATR == 1 ? 4 : 3)
 template <bool DGRAD, int ATR, int EPI>
 static int dispatch_gather_fused(const float* src, const float* wm, float* dst, const GatherGeom& g0, const GatherFuse& F,
                                  hipStream_t st) {
@@ -741,8 +776,13 @@ static int dispatch_gather_fused(const float* src, const float* wm, float* dst, 
   g.flags |= GF_VEC_EPI;
   static const int small_grid = []() { const char* e = getenv("EDRL_NARROW_BELOW"); return e ? atoi(e) : 512; }();
   const bool narrow = g.NC <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(g.NC, 128) < small_grid);
-  if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI>(src, wm, dst, nullptr, nullptr, g, st, &F);
-  return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI>(src, wm, dst, nullptr, nullptr, g, st, &F);
+  const bool mask = !(g.KH == 1 && g.KW == 1 && g.pad == 0);   // 1x1 / pad 0: no padding taps, no masked rows below M
+  if (narrow) {
+    if (mask) return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
+    return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
+  }
+  if (mask) return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
+  return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
 }
 
 template <int BM, int BN, bool DGRAD, bool VEC>
@@ -835,10 +875,12 @@ struct WgradGeom {
 // Rows outside the split's pixel range / padding taps are forced to exactly 0 after the transform.
 struct WgradFuse {
   const float* dy2;                 // DYT 2: raw conv output of this layer (same geometry as dy)
-  const float* bcoef;               // DYT 2: [4][Co] = A, K1, K2, mean
-  const float* xcoef;               // XT 1:  [4][SC] = mean, rstd, scale, shift of the producing BatchNorm
+  const float* bcoef;               // DYT 2: [4][Co] = A, nK2, C2, mean
+  const float* xcoef;               // XT 1:  [5][SC] = mean, rstd, scale, shift, shift2 of the producing BatchNorm
 };
-template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0>
+// MASKX (XT 1): the conv has padding taps, which must read as exactly 0 after the transform (3x3); a 1x1 / pad-0 layer's only
+// invalid X rows are those past the end of the tensor, and they meet dY rows that DYT has already zeroed.
+template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g, WgradFuse F) {
   static_assert((DYT == 0 && XT == 0) || FASTLD, "operand transforms ride on the buffer-descriptor path");
@@ -903,8 +945,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   int dw_step = 0, dh_step = 0;
   __amdgpu_buffer_rsrc_t rs_dy, rs_x, rs_dy2;
   unsigned dy_last = 0, x_last = 0;            // last in-range 16-byte offset of each descriptor
-  f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;   // DYT 2 parameters of this thread's 4 output channels
-  f32x4 xm = q0, xs = q0, xb = q0;                              // XT 1 parameters of this thread's 4 input channels
+  f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;            // DYT 2 parameters (A, nK2, C2) of this thread's 4 output channels
+  f32x4 xs = q0, xb = q0;                                       // XT 1 parameters (scale, shift2) of this thread's 4 input channels
   bool a_ok[A_LD], b_ok[B_LD];
   f32x4 a2_st[DYT == 2 ? A_LD : 1];
   if constexpr (FASTLD) {
@@ -922,14 +964,12 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
         q0 = *reinterpret_cast<const f32x4*>(F.bcoef + co);
         q1 = *reinterpret_cast<const f32x4*>(F.bcoef + g.Co + co);
         q2 = *reinterpret_cast<const f32x4*>(F.bcoef + 2 * g.Co + co);
-        q3 = *reinterpret_cast<const f32x4*>(F.bcoef + 3 * g.Co + co);
       }
     }
     if constexpr (XT == 1) {
       if (kvalid) {
-        xm = *reinterpret_cast<const f32x4*>(F.xcoef + kc);
         xs = *reinterpret_cast<const f32x4*>(F.xcoef + 2 * g.SC + kc);
-        xb = *reinterpret_cast<const f32x4*>(F.xcoef + 3 * g.SC + kc);
+        xb = *reinterpret_cast<const f32x4*>(F.xcoef + 4 * g.SC + kc);
       }
     }
     const long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
@@ -972,7 +1012,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
       const bool ok = kvalid && (unsigned)b_ih[i] < (unsigned)g.SH && (unsigned)b_iw[i] < (unsigned)g.SW;
       const unsigned off = ok ? b_roff[i] + (unsigned)tapconst : OOB;
       b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
-      if constexpr (XT == 1) b_ok[i] = off <= x_last;
+      if constexpr (XT == 1 && MASKX) b_ok[i] = off <= x_last;
       b_iw[i] += dw_step; b_ih[i] += dh_step; b_roff[i] += c_step;
       const bool w = b_iw[i] >= iw_lim;
       b_iw[i] -= w ? g.OW * g.stride : 0; b_ih[i] += w ? g.stride : 0; b_roff[i] += w ? c_wrapw : 0u;
@@ -1050,22 +1090,30 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int row = (tid + 256 * i) / AC4;
-      f32x4 v = a_st[i];
-      if constexpr (DYT == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a_ok[i] ? edrl_bn_bwd_dx(v[e], a2_st[i][e], q0[e], q1[e], q2[e], q3[e]) : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(a + row * LDA + ac4 * 4) = v;
+      *reinterpret_cast<f32x4*>(a + row * LDA + ac4 * 4) = a_st[i];
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int row = (tid + 256 * i) / BC4;
-      f32x4 v = b_st[i];
-      if constexpr (XT == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = b_ok[i] ? edrl_bn_relu(v[e], xm[e], xs[e], xb[e]) : 0.f;
+      *reinterpret_cast<f32x4*>(b + row * LDB + bc4 * 4) = b_st[i];
+    }
+  };
+  // Operand transforms on the staged registers, one element at a time: in the K loop they are issued behind the MFMAs of the
+  // tile's second half (matrix-pipe shadow) instead of between the end of the chain and the workgroup barrier.
+  constexpr int EL_A = DYT == 2 ? A_LD : 0, EL_B = XT == 1 ? B_LD : 0, EL = EL_A + EL_B;     // 4-channel pieces
+  const f32x4 zero4w = {0.f, 0.f, 0.f, 0.f};
+  auto transform_piece = [&](int el) {          // el compile-time after unrolling
+    if (el < EL_A) {
+      if constexpr (DYT == 2) {
+        const f32x4 v = edrl_bn_bwd_dx2(a_st[el], a2_st[el], q0, q1, q2);
+        a_st[el] = a_ok[el] ? v : zero4w;
       }
-      *reinterpret_cast<f32x4*>(b + row * LDB + bc4 * 4) = v;
+    } else if (el < EL) {
+      if constexpr (XT == 1) {
+        const int i = el - EL_A;
+        const f32x4 v = edrl_bn_relu2(b_st[i], xs, xb);
+        if constexpr (MASKX) b_st[i] = b_ok[i] ? v : zero4w; else b_st[i] = v;
+      }
     }
   };
 
@@ -1080,6 +1128,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   const int li = lane & 31, lh = lane >> 5;
   if (t_begin < t_end) {
     load_tile(t_begin);
+#pragma unroll
+    for (int el = 0; el < EL; ++el) transform_piece(el);
     store_tile(0);
     __syncthreads();
     for (long t = t_begin; t < t_end; ++t) {
@@ -1111,8 +1161,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        // one 4-channel piece of the NEXT tile's operand transform rides behind the MFMAs of each of the last EL k-steps
+        // (its VALU instructions are scheduled as one more group of the step's pipeline)
+        const bool xf = EL > 0 && sidx >= BKT / 2 - EL;
+        if (xf) transform_piece(sidx - (BKT / 2 - EL));   // (unconditional: on the last tile it re-transforms stale registers that are never stored; a branch here would split the MFMA chain's scheduling region)
         if (sidx + 1 < BKT / 2) __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // DS reads (read2 pairs)
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                             // MFMAs
+        if (xf) __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);                                          // transform VALU
       }
       if (t + 1 < t_end) store_tile(buf ^ 1);
       __syncthreads();
@@ -1165,11 +1220,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #define WG_BK 16
 #define WG_OCC 4
 #define WG_OCC_FUSED 3
-template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0>
+template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st, const WgradFuse* fuse = nullptr) {
   const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (DYT || XT) ? WG_OCC_FUSED : WG_OCC, FASTLD, DYT, XT>;
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (DYT || XT) ? WG_OCC_FUSED : WG_OCC, FASTLD, DYT, XT, MASKX>;
   WgradFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   static bool attr_set = false;
@@ -1328,13 +1383,13 @@ static bool wgrad_fast_ok(const float* dy, const float* x, int Hi, int Wi, int C
          (span / ((long)Ho * Wo) + 2) * Hi * Wi * ld_x * 4 < (1L << 31);
 }
 
-template <int DYT, int XT>
+template <int DYT, int XT, bool MASKX>
 static int wgrad_fused_launch(const float* dy, const float* x, float* ws, const WgradGeom& g, int bm, int bn, int splits,
                               const WgradFuse& F, hipStream_t st) {
-  if (bm == 64 && bn == 64) return launch_wgrad<64, 64, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
-  if (bm == 64) return launch_wgrad<64, 128, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
-  if (bn == 64) return launch_wgrad<128, 64, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
-  return launch_wgrad<128, 128, true, true, DYT, XT>(dy, x, ws, g, splits, st, &F);
+  if (bm == 64 && bn == 64) return launch_wgrad<64, 64, true, true, DYT, XT, MASKX>(dy, x, ws, g, splits, st, &F);
+  if (bm == 64) return launch_wgrad<64, 128, true, true, DYT, XT, MASKX>(dy, x, ws, g, splits, st, &F);
+  if (bn == 64) return launch_wgrad<128, 64, true, true, DYT, XT, MASKX>(dy, x, ws, g, splits, st, &F);
+  return launch_wgrad<128, 128, true, true, DYT, XT, MASKX>(dy, x, ws, g, splits, st, &F);
 }
 
 static int wgrad_impl(const float* dy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int N, int Hi,
@@ -1362,8 +1417,10 @@ static int wgrad_impl(const float* dy, const float* x, float* dw, float* workspa
     if (!fast_ok) return EDRL_EINVAL;     // the fused operands exist on the buffer-load path only
     const bool dyt = fuse->dy2 != nullptr, xt = fuse->xcoef != nullptr;
     if (dyt && (((uintptr_t)fuse->dy2 & 15) != 0)) return EDRL_EINVAL;
-    if (dyt && xt) rc = wgrad_fused_launch<2, 1>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
-    else if (dyt) rc = wgrad_fused_launch<2, 0>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
+    const bool maskx = !(KH == 1 && KW == 1 && pad == 0);
+    if (dyt && xt && maskx) rc = wgrad_fused_launch<2, 1, true>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
+    else if (dyt && xt) rc = wgrad_fused_launch<2, 1, false>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
+    else if (dyt) rc = wgrad_fused_launch<2, 0, true>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
     else return EDRL_EINVAL;
   } else if (fast) {
     if (bm == 64 && bn == 64) rc = launch_wgrad<64, 64, true, true>(dy, x, workspace, g, splits, st);
@@ -1438,7 +1495,7 @@ int edrl_conv2d_nhwc_fwd_bnin_stats_f32(const float* x, const float* in_fcoef, c
   g.stat_part = stat_part; g.stat_shift = nullptr;
   GatherFuse F;
   memset(&F, 0, sizeof(F));
-  F.ap0 = in_fcoef; F.ap1 = in_fcoef + 2 * (long)Ci; F.ap2 = in_fcoef + 3 * (long)Ci;
+  F.acoef = in_fcoef;
   return dispatch_gather_fused<false, 1, 0>(x, w, y, g, F, st);
 }
 
@@ -1485,11 +1542,9 @@ int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g_in, const float* yraw, const fl
   GatherFuse F;
   memset(&F, 0, sizeof(F));
   F.src2 = yraw;
-  F.ap0 = bcoef; F.ap1 = bcoef + (long)Co; F.ap2 = bcoef + 2 * (long)Co; F.ap3 = bcoef + 3 * (long)Co;
+  F.acoef = bcoef;
   if (ep_raw) {
-    F.ep_x = ep_raw; F.ld_ep = Ci; F.ep_mask = ep_mask;
-    F.ep_mean = ep_fcoef; F.ep_rstd = ep_fcoef + (long)Ci; F.ep_scale = ep_fcoef + 2 * (long)Ci; F.ep_shift = ep_fcoef + 3 * (long)Ci;
-    F.ep_part = ep_part;
+    F.ep_x = ep_raw; F.ld_ep = Ci; F.ep_mask = ep_mask; F.ep_fcoef = ep_fcoef; F.ep_part = ep_part;
   }
   int chunk0 = 0;
   for (int ph = 0; ph < stride; ++ph)

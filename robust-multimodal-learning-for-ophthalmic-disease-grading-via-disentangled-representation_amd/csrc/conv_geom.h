@@ -30,18 +30,13 @@ struct GatherGeom {
 // Fused-BatchNorm operands of the gather kernels (conv_gather_*_kernel<..., ATR, EPI>).
 struct GatherFuse {
   const void* src2;            // ATR 2: raw conv output paired with the masked gradient in `src` (same geometry and ld)
-  const float* ap0;            // ATR 1: mean   | ATR 2: A  = gamma*rstd           (all indexed by SOURCE channel)
-  const float* ap1;            // ATR 1: scale  | ATR 2: K1 = A*mean(g)
-  const float* ap2;            // ATR 1: shift  | ATR 2: K2 = A*rstd*mean(g*xhat)
-  const float* ap3;            //               | ATR 2: mean
+  const float* acoef;          // ATR 1: fcoef [5][SC] = {mean, rstd, scale, shift, shift2} of the producing BatchNorm
+                               // ATR 2: bcoef [4][SC] = {A, nK2, C2, mean} of this layer's BatchNorm backward
   const void* ep_x;            // EPI 1: raw conv output the destination tensor is the (post-ReLU) gradient of
   long ld_ep;                  //        its pixel stride (elements)
   const unsigned char* ep_mask;//        ReLU sign bytes [pixel][NC/4], or NULL: recompute the decision from ep_x when GF_EPI_RELU
-  const float* ep_mean;        //        per DESTINATION channel
-  const float* ep_rstd;
-  const float* ep_scale;
-  const float* ep_shift;
-  float* ep_part;              //        [chunks][2][NC] partial sums (sum g, sum g*xhat), one chunk per 128-row tile
+  const float* ep_fcoef;       //        fcoef [5][NC] of that BatchNorm
+  float* ep_part;              //        [chunks][2][NC] partial sums (sum g, sum g*x), one chunk per 128-row tile
   int ep_chunk0;               //        first chunk of this launch (parity classes of a strided data gradient)
 };
 

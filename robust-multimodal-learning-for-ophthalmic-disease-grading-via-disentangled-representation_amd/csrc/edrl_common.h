@@ -20,17 +20,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (e__ != hipSuccess) return (int)e__;      \
   } while (0)
 
-// BatchNorm forms shared by every kernel that applies them, so that the ReLU decision recomputed in backward is bit-identical
-// to the one taken in forward (one fused multiply-add on the mean-subtracted value, everywhere).
+// BatchNorm forms shared by the kernels that apply them on the fly.  Next to the fp32 MFMA every VALU instruction costs
+// matrix-pipe time (both run on the SIMD's fp32 lanes), so the fused operand transforms are single packed FMAs:
+//   activation   relu(x*scale + shift2),  shift2 = shift - mean*scale          (fcoef rows 2 and 4)
+//   d_raw        A*g + nK2*x + C2,        nK2 = -A*rstd*mean(g*xhat), C2 = -nK2*mean - A*mean(g)   (bcoef rows 0..2)
+// The ReLU decision recomputed in backward uses the identical expression, hence the identical bits.
 __device__ __forceinline__ float edrl_bn_pre(float x, float mean, float scale, float shift) {
   return __builtin_fmaf(x - mean, scale, shift);
 }
-__device__ __forceinline__ float edrl_bn_relu(float x, float mean, float scale, float shift) {
-  return fmaxf(edrl_bn_pre(x, mean, scale, shift), 0.f);
+__device__ __forceinline__ f32x4 edrl_bn_pre2(f32x4 x, f32x4 scale, f32x4 shift2) {
+  return __builtin_elementwise_fma(x, scale, shift2);
 }
-// d_raw = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) = A*g - K1 - K2*(x - mean)
-__device__ __forceinline__ float edrl_bn_bwd_dx(float g, float x, float A, float K1, float K2, float mean) {
-  return __builtin_fmaf(-K2, x - mean, __builtin_fmaf(A, g, -K1));
+__device__ __forceinline__ f32x4 edrl_bn_relu2(f32x4 x, f32x4 scale, f32x4 shift2) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return __builtin_elementwise_max(edrl_bn_pre2(x, scale, shift2), z);
+}
+__device__ __forceinline__ f32x4 edrl_bn_bwd_dx2(f32x4 g, f32x4 x, f32x4 A, f32x4 nK2, f32x4 C2) {
+  return __builtin_elementwise_fma(nK2, x, __builtin_elementwise_fma(A, g, C2));
 }
 
 static inline int edrl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

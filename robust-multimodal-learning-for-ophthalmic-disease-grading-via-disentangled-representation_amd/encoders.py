@@ -118,14 +118,13 @@ _FUSE_BN = os.environ.get("EDRL_FUSE_BN", "1") != "0"
 
 
 def _fcoef_from_partials(part, chunks, M, C, bn):
-    """conv-epilogue chunk partials -> fcoef [4][C] = {mean, rstd, scale, shift}; running statistics updated in place."""
+    """conv-epilogue chunk partials -> fcoef [5][C] = {mean, rstd, scale, shift, shift2}; running statistics updated in place."""
     dev = part.device
-    fc = torch.empty((4, C), device=dev, dtype=torch.float32)
+    fc = torch.empty((5, C), device=dev, dtype=torch.float32)
     gbytes = L.query("edrl_bn_finalize_group_ws_bytes", chunks, C)
     gws = torch.empty(max(gbytes // 8, 1), device=dev, dtype=torch.float64)
-    L.call("edrl_bn_finalize_partials_f32", P(part), chunks, 128, M, C, P(bn["weight"]), P(bn["bias"]),
-           P(bn["running_mean"]), P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(fc[0]), P(fc[1]),
-           P(fc[2]), P(fc[3]), P(gws), gbytes)
+    L.call("edrl_bn_finalize_fcoef_f32", P(part), chunks, 128, M, C, P(bn["weight"]), P(bn["bias"]),
+           P(bn["running_mean"]), P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(fc), P(gws), gbytes)
     return fc
 
 
@@ -154,13 +153,13 @@ def _bn_bwd_reduce(dout, mask, raw, fcoef, want_g):
 
 
 def _dbg_act(raw, fc):
-    """(tests only) the activation a fused consumer forms on the fly: relu(fma(x-mean, scale, shift))."""
-    return torch.relu(torch.addcmul(fc[3], raw - fc[0], fc[2]))
+    """(tests only) the activation a fused consumer forms on the fly: relu(x*scale + shift2)."""
+    return torch.relu(torch.addcmul(fc[4], raw, fc[2]))
 
 
 def _dbg_draw(g, raw, bc):
-    """(tests only) d_raw = A*g - K1 - K2*(x-mean) as the fused consumers form it."""
-    return bc[0] * g - bc[1] - bc[2] * (raw - bc[3])
+    """(tests only) d_raw = A*g + nK2*x + C2 as the fused consumers form it."""
+    return bc[0] * g + bc[1] * raw + bc[2]
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -392,7 +391,7 @@ class _TrunkFn(torch.autograd.Function):
             return (raw_lo, kl, fc_lo, True), keep
 
         def recompute_keep(raw, fc):     # (tests) the pre-activation whose sign the epilogue re-derives
-            return lambda: torch.addcmul(fc[3], raw - fc[0], fc[2])
+            return lambda: torch.addcmul(fc[4], raw, fc[2])
 
         grad_in = ("plain", dout.contiguous())
         for bi in range(len(T.blocks) - 1, -1, -1):
