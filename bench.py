@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — EDRL training-step throughput on MI355X (contract: see the task's bench.py section).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C0|C2x] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C0|C1|C2|C3|C4|C1-3D] [--batch B]
   N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one synthetic batch: zero_grad -> forward(low view) ->
 forward(high view) -> MK_MMD -> backward -> (DP gradient all-reduce) -> Adam.step
 (fusion_train.py:189-224).  Inputs are resident in HBM before the timed region.  Workload at N=1 is
 BASELINE.json configs[1] (C1): per-GPU batch 32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32.
+At N>1 it is configs[3] (C3): the same shapes at per-GPU batch 64 (global 512 at N=8), data parallel, with the residual
+blocks' outputs rebuilt in backward so that the fp32 activations of 2 x 64 x 33 images fit one GPU's 288 GB.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -27,12 +29,17 @@ CONFIGS = {
     # BASELINE.json configs[2]; NOT the default bench line (the metric is quoted on C1/fp32): bf16 MFMA encoders
     # (bf16 activations/gradients, fp32 accumulate + fp32 BatchNorm statistics + fp32 weights/Adam), fp32 head.
     "C2": (64, 50, 224, 32, "bf16", "C2: B=64/GPU, ResNet-50 encoders on the bf16 MFMA path, 224x224 fundus + 32-slice OCT"),
+    # BASELINE.json configs[3]: data parallel, global batch 512 on 8 GPUs = 64 per GPU, fp32 like C1; the default for --gpus N > 1.
+    # Activations of 2 views x 64 x (1 + 32) images exceed 288 GB unless the block outputs are rebuilt in backward (RECOMPUTE).
+    "C3": (64, 50, 224, 32, "fp32", "C3: B=64/GPU (global 512 at 8 GPUs), ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32, "
+                                    "block outputs recomputed in backward"),
     # BASELINE.json configs[4] per-GPU shape (an 8-GPU config; B=3 is the largest per-GPU batch whose saved activations
     # fit 288 GB): 512x512 fundus + 128-slice OCT, second view with the OCT volume dropped (zeros), bf16 encoders.
     # C1 shapes with the true 3-D-conv OCT encoder (ResNet3D-18 over the 32x224x224 volume)
     "C1-3D": (32, 50, 224, 32, "fp32", "C1-3D: B=32/GPU, ResNet-50 fundus encoder + ResNet3D-18 OCT volume encoder, 224x224 fundus + 32-slice OCT, fp32"),
     "C4": (3, 50, 512, 128, "bf16", "C4: B=3/GPU, ResNet-50 bf16 encoders, 512x512 fundus + 128-slice OCT, OCT-dropped second view"),
 }
+RECOMPUTE = {"C3"}     # configs that run with args.activation_recompute (encoders.ResNetTrunk.recompute_out)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense, 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 
@@ -42,7 +49,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C1", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: C1 at --gpus 1, C3 at --gpus N > 1")
+    ap.add_argument("--recompute", action="store_true", help="force args.activation_recompute (C3 sets it)")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -72,11 +80,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if a.config is None:
+        a.config = "C1" if a.gpus == 1 else "C3"
     B, depth, HW, S, enc_dtype, desc = CONFIGS[a.config]
+    recompute = a.recompute or a.config in RECOMPUTE
     if a.batch:
         B = a.batch
         desc = desc.replace(f"B={CONFIGS[a.config][0]}/GPU", f"B={B}/GPU (override)")
-    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, strict_labels=False,
+    # strict_labels keeps its default ("deferred": violation flag on the device, raised by raise_on_bad_labels() below)
+    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, activation_recompute=recompute,
                                  encoder_dtype=enc_dtype, oct_encoder="3d" if a.config == "C1-3D" else "slices", oct3d_depth=18)
     torch.manual_seed(0)
     model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
@@ -173,8 +185,15 @@ def main():
                     res["roofline"]["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
                                                "HBM-bound (50-250 FLOP/B against a ~450 FLOP/B ridge), only the 3x3 layers of "
                                                "stages 2-4 are MFMA-bound (~790 TFLOP/s there): profiles/README.md")
-            res["kernels"] = {k: {"launches": v["launches"], "calls": v["calls"], "ms_total": round(v["ms"], 3),
-                                  "tflops": round(v["tflops"], 3)} for k, v in ks.items()}
+            res["kernels"] = {}
+            for k, v in ks.items():
+                e = {"launches": v["launches"], "calls": v["calls"], "ms_total": round(v["ms"], 3)}
+                if "GBps" in v:      # HBM-bound passes: algorithmic bytes / HIP-event time against the 8 TB/s HBM3E spec
+                    e.update(bound="hbm", GBps=round(v["GBps"], 1), frac_of_8TBps=round(v["GBps"] / 8000.0, 4),
+                             algorithmic_bytes=v["bytes"])
+                else:
+                    e.update(bound="mfma", tflops=round(v["tflops"], 3))
+                res["kernels"][k] = e
         if "roofline" in res:
             # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py);
             # only quoted when those passes ran this very workload.
@@ -182,42 +201,69 @@ def main():
                 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_c1.json")))
                 if pm.get("workload") == desc and "conv_gather" in pm.get("kernels", {}):
                     res["roofline"]["traffic"] = round(pm["kernels"]["conv_gather"]["hbm_bytes_per_launch"])
-                    res["roofline"]["traffic_source"] = "profiles/pmc_traffic_c1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                    res["roofline"]["traffic_source"] = ("static: profiles/pmc_traffic_c1.json -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                         "passes of this same command, collected separately (not measured in this run)")
             except (OSError, ValueError):
                 pass
         if overlap is not None:
             res["view_overlap"] = overlap
+        if recompute:
+            res["config"]["activation_recompute"] = True
+        if world > 1:
+            res["scaling_note"] = ("weak: per-GPU batch fixed at %d for every N > 1; the N = 1 line of this script is C1 (per-GPU batch 32), "
+                                   "BASELINE.json's single-GPU config" % B)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, depth, HW, S)
+            res["cpu_baseline"] = cpu_baseline(depth, HW, S, dev)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, depth, HW, S):
-    """The oracle (torch-CPU restatement, `kind: port`) timed on this host's cores on a BOUNDED sample of the
-    same workload: one full step (2 views fwd+bwd + MK_MMD + Adam) at batch 2 (the smallest batch train-mode
-    BatchNorm admits) with min(S, 16) OCT slices per sample, same encoders and image size.  The rate is scaled
-    to the workload's S slices by the conv+linear MAC ratio of one sample (stated in `sample`)."""
+def _cpu_leg(depth, HW, S, Bc, dev, warm=2, timed=5):
+    """Median of `timed` full oracle steps after `warm` warm-ups (SURVEY.md 8d protocol) -> (images/s, seconds per step)."""
+    import statistics
     import torch
     import edrl_amd
-    from oracle import host_cores, step_oracle as SO
+    from oracle import step_oracle as SO
+    args = types.SimpleNamespace(mode="train", batch_size=Bc, encoder_depth=depth)
+    torch.manual_seed(0)
+    proto = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()      # only its initial weights are used (copied to the host)
+    orc = SO.OracleEDRL(proto, dtype=torch.float32)
+    del proto
+    data, y = edrl_amd.synthetic_batch(Bc, HW, HW, S, device="cpu", seed=99)
+    N2 = (HW // 32) ** 2
+    n1, n2 = SO.make_noise(1, Bc, N2, S), SO.make_noise(2, Bc, N2, S)
+    state, times = {}, []
+    for i in range(warm + timed):
+        t0 = time.perf_counter()
+        orc.train_step(data, y, n1, n2, lr=1e-4, adam_state=state)
+        if i >= warm:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return Bc / med, med
+
+
+def cpu_baseline(depth, HW, S, dev):
+    """The oracle (torch-CPU restatement of the reference step, `kind: port`) timed on this host's cores, SURVEY.md 8(d)
+    protocol: 2 warm-up steps then the median of 5 full steps (2 views fwd+bwd + MK_MMD + Adam), all host threads,
+      * at this workload's shapes (encoders, image size, ALL S slices) with the per-GPU batch reduced to 2 (the smallest batch
+        train-mode BatchNorm1d admits) -- the bounded sample whose rate is `value` (on a CPU the step is conv-bound and linear
+        in the image count, so images/s does not depend on the batch to first order);
+      * at BASELINE.json configs[0] (C0: B=2, ResNet-18, 224x224 + 16 slices), the reference's own CPU-runnable case, in full."""
+    import torch
+    from oracle import host_cores
     cores = min(host_cores(), 64)
     torch.set_num_threads(cores)
-    Bc, Ss = 2, min(S, 16)
-    print(f"[bench] cpu_baseline: oracle step on {cores} host threads, batch {Bc}, {Ss} slices ...", file=sys.stderr, flush=True)
-    orc = SO.OracleEDRL(model, dtype=torch.float32)
-    orc.batch_size = Bc
-    data, y = edrl_amd.synthetic_batch(Bc, HW, HW, Ss, device="cpu", seed=99)
-    N2 = (HW // 32) ** 2
-    n1, n2 = SO.make_noise(1, Bc, N2, Ss), SO.make_noise(2, Bc, N2, Ss)
-    t0 = time.perf_counter()
-    orc.train_step(data, y, n1, n2, lr=1e-4, adam_state={})
-    dt = time.perf_counter() - t0
-    ratio = (1.0 + S) / (1.0 + Ss)          # encoder passes per sample: 1 fundus + S slices (same trunk MACs/image +-2%)
-    return {"value": round(Bc / (dt * ratio), 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 full step at batch {Bc}, resnet{depth}, {HW}x{HW} fundus + {Ss} of {S} OCT slices, torch-CPU fp32 "
-                      f"oracle: {dt:.1f} s measured ({Bc / dt:.4f} images/s at {Ss} slices), scaled x1/{ratio:.2f} to {S} slices"}
+    print(f"[bench] cpu_baseline: oracle steps on {cores} host threads (2 warm-ups + median of 5), workload shapes at batch 2 ...",
+          file=sys.stderr, flush=True)
+    v1, s1 = _cpu_leg(depth, HW, S, 2, dev)
+    print(f"[bench] cpu_baseline: {v1:.4f} images/s ({s1:.2f} s/step); C0 in full ...", file=sys.stderr, flush=True)
+    v0, s0 = _cpu_leg(18, 224, 16, 2, dev)
+    return {"value": round(v1, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"median of 5 full steps after 2 warm-ups, torch-CPU fp32 oracle on {cores} threads: resnet{depth}, {HW}x{HW} fundus + "
+                      f"{S} OCT slices at batch 2 (reduced from the workload's batch; {s1:.2f} s/step)",
+            "c0": {"value": round(v0, 4), "unit": "images/s", "s_per_step": round(s0, 3),
+                   "workload": "BASELINE.json configs[0]: B=2, ResNet-18, 224x224 fundus + 16-slice OCT, fp32, full shapes"}}
 
 
 if __name__ == "__main__":

@@ -148,7 +148,8 @@ def _bn_bwd_reduce(dout, mask, raw, fcoef, want_g):
     M = raw.numel() // C
     g = torch.empty_like(raw) if want_g else None
     ws, nbytes = _bn_ws(M, C, raw.device)
-    L.call("edrl_bn_bwd_reduce_f32", P(dout), P(mask), P(raw), P(fcoef), P(g), P(ws), nbytes, M, C)
+    ops.call_timed_bytes("bn_bwd_reduce", M * C * (8.0 + (4.0 if want_g else 0.0) + (0.25 if mask is not None else 0.0)),
+                         "edrl_bn_bwd_reduce_f32", P(dout), P(mask), P(raw), P(fcoef), P(g), P(ws), nbytes, M, C)
     return (g if want_g else dout), ws, (M + 1023) // 1024, 3
 
 
@@ -234,11 +235,16 @@ class _TrunkFn(torch.autograd.Function):
         if cap is not None:
             cap["maxpool"] = dict(inp=a0, out=p0, idx=idx)
         cur = p0
+        prev_fused = False
         for blk in T.blocks:
             pre, s = blk["name"], blk["stride"]
-            rec = {"x": cur}
+            # recompute mode: the input of a block that follows a fused block is that block's output, which backward
+            # rebuilds from the raw tensors (see get_x in backward) -- it is not kept
+            rec = {"x": None if (T.recompute_out and prev_fused and cap is None) else cur}
+            prev_fused = False
             if block_fused_ok(blk, cur):
                 rec["fused"] = True
+                prev_fused = True
                 cd = fd = None
                 if blk["downsample"]:
                     cd, fd = cf(pre + ".downsample.0", pre + ".downsample.1", cur, None, s, 0)
@@ -258,7 +264,8 @@ class _TrunkFn(torch.autograd.Function):
                 Ml = cl.numel() // Cl
                 out = torch.empty_like(cl)
                 kl = torch.empty((Ml, Cl // 4), device=cl.device, dtype=torch.uint8)
-                L.call("edrl_bn_apply_res_f32", P(cl), P(fl), P(cd if cd is not None else cur), P(fd), P(out), P(kl), Ml, Cl, 1)
+                ops.call_timed_bytes("bn_apply_res", Ml * Cl * 12.25, "edrl_bn_apply_res_f32", P(cl), P(fl),
+                                     P(cd if cd is not None else cur), P(fd), P(out), P(kl), Ml, Cl, 1)   # 2 reads + 1 write + sign bytes
                 rec.update(kl=kl)
                 if cap is not None:
                     cap[last].update(out=out, mask=kl, residual=(cur if cd is None else
@@ -393,13 +400,36 @@ class _TrunkFn(torch.autograd.Function):
         def recompute_keep(raw, fc):     # (tests) the pre-activation whose sign the epilogue re-derives
             return lambda: torch.addcmul(fc[4], raw, fc[2])
 
+        # ---- recompute mode (T.recompute_out): block outputs are rebuilt from the stored raw tensors, one elementwise pass
+        # each (the forward's own edrl_bn_apply_res_f32, bit-identical), a residual stage at a time; out_j is dropped as soon
+        # as block j+1 is done.
+        out_cache = {}
+
+        def get_out(j):
+            t = out_cache.get(j)
+            if t is None:
+                rj = saved[T.blocks[j]["name"]]
+                cl, fl = (rj["c3"], rj["f3"]) if T.kind == "bottleneck" else (rj["c2"], rj["f2"])
+                res, rfc = (rj["cd"], rj["fd"]) if T.blocks[j]["downsample"] else (get_x(j), None)
+                t = torch.empty_like(cl)
+                Cl = cl.shape[-1]
+                ops.call_timed_bytes("bn_apply_res", cl.numel() * 12.0, "edrl_bn_apply_res_f32", P(cl), P(fl), P(res), P(rfc),
+                                     P(t), None, cl.numel() // Cl, Cl, 1)
+                out_cache[j] = t
+            return t
+
+        def get_x(j):
+            xj = saved[T.blocks[j]["name"]]["x"]
+            return xj if xj is not None else get_out(j - 1)
+
         grad_in = ("plain", dout.contiguous())
         for bi in range(len(T.blocks) - 1, -1, -1):
             blk = T.blocks[bi]
             pre, s = blk["name"], blk["stride"]
             ep_lo, keep_lo = lower_ep(bi)
             rec = saved[pre]
-            xin = rec["x"]
+            xin = get_x(bi)
+            out_cache.pop(bi, None)
             if rec.get("fused"):
                 bott = T.kind == "bottleneck"
                 last, last_bn = (pre + ".conv3", pre + ".bn3") if bott else (pre + ".conv2", pre + ".bn2")
@@ -704,6 +734,9 @@ class ResNetTrunk(nn.Module):
         self.param_names = [n for n, _ in self.named_parameters()]
         self._capture = None
         self._wt_cache = {}
+        # True: do not keep the residual blocks' outputs for backward (rebuilt there from the raw conv outputs: one extra
+        # elementwise pass per block, -30 % activation memory) -- what lets BASELINE.json's B=64/GPU fp32 shapes fit 288 GB
+        self.recompute_out = os.environ.get("EDRL_RECOMPUTE_OUT", "0") == "1"
 
     # parameters are registered under dotted torchvision-style names with '.' -> '__' for attribute safety
     def _reg(self, name, tensor, buffer=False):

@@ -259,8 +259,12 @@ class DILR(nn.Module):
 class MedFusion(nn.Module):
     """MedFusion(classes, modalties, classifiers_dims, args): args.mode, args.batch_size (per-GPU batch) as in
     the reference; optional args.encoder_depth (18|34|50, default 50), args.encoder_dtype ("fp32"|"bf16"),
-    args.rng ("device"|"reference"),
-    args.strict_labels (default True: raise on labels outside {0,1} like the reference's KeyError)."""
+    args.rng ("device"|"reference"), args.activation_recompute (bool: rebuild the residual blocks' outputs in backward
+    instead of keeping them, encoders.ResNetTrunk.recompute_out),
+    args.strict_labels: labels outside {0,1} raise KeyError like the reference's proxies_dict lookup (fusion_net.py:101,227);
+    "deferred" (default) records the violation on the device with no host sync in the step and raises from
+    raise_on_bad_labels() (train() calls it at the end of the epoch, val() after the loop); True raises inside forward (one
+    blocking .item() per forward); False never raises."""
 
     def __init__(self, classes, modalties, classifiers_dims, args):
         super().__init__()
@@ -286,7 +290,9 @@ class MedFusion(nn.Module):
         self.DILR = DILR(args, common_ratio=0.5)
         self.args = args
         self.rng = getattr(args, "rng", "device")
-        self.strict_labels = getattr(args, "strict_labels", True)
+        self.strict_labels = getattr(args, "strict_labels", "deferred")
+        for t in self.trunks():
+            t.recompute_out = bool(getattr(args, "activation_recompute", t.recompute_out))
         self.EPRL_fundus.rng = self.EPRL_oct.rng = self.PoE.rng = self.rng
         self._label_flag = None
 
@@ -304,11 +310,11 @@ class MedFusion(nn.Module):
         if self._label_flag is None or self._label_flag.device != y.device:
             self._label_flag = torch.zeros(1, dtype=torch.int32, device=y.device)
         L.call("edrl_check_labels", L.ptr(y), y.shape[0], self.num_classes, L.ptr(self._label_flag))
-        if self.strict_labels:
+        if self.strict_labels is True:
             self.raise_on_bad_labels()
 
     def raise_on_bad_labels(self):
-        if self._label_flag is not None and int(self._label_flag.item()) != 0:
+        if self.strict_labels is not False and self._label_flag is not None and int(self._label_flag.item()) != 0:
             self._label_flag.zero_()
             raise KeyError("label outside the proxy dictionary {0, 1} (fusion_net.py:101,227)")
 

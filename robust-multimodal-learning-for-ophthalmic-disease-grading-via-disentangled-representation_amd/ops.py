@@ -41,25 +41,29 @@ def _ld(x2):
 
 # ------------------------------------------------------------------ live kernel timing (bench.py roofline leg)
 class KernelTimer:
-    """HIP-event bracketing of the MFMA contraction launches on the stream they run on.
-    kind -> [algorithmic flops, [(start_event, end_event), ...]]."""
+    """HIP-event bracketing of launches on the stream they run on.
+    kind -> [algorithmic flops, [(start_event, end_event), ...], kernel launches, algorithmic bytes]."""
 
     def __init__(self):
         self.records = {}
 
-    def add(self, kind, flops, e0, e1, kernels=1):
-        r = self.records.setdefault(kind, [0.0, [], 0])
+    def add(self, kind, flops, e0, e1, kernels=1, nbytes=0.0):
+        r = self.records.setdefault(kind, [0.0, [], 0, 0.0])
         r[0] += flops
         r[1].append((e0, e1))
         r[2] += kernels
+        r[3] += nbytes
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, (flops, evs, kernels) in self.records.items():
+        for kind, (flops, evs, kernels, nbytes) in self.records.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)
             out[kind] = {"launches": kernels, "calls": len(evs), "flops": flops, "ms": ms,
                          "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+            if nbytes:
+                out[kind]["bytes"] = nbytes
+                out[kind]["GBps"] = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return out
 
 
@@ -82,6 +86,18 @@ def _launch_timed(kind, flops, name, *args, kernels=1):
     L.call(name, *args)
     e1.record()
     _timer.add(kind, flops, e0, e1, kernels)
+
+
+def call_timed_bytes(kind, nbytes, name, *args, kernels=1):
+    """An HBM-bound launcher bracketed like _launch_timed; `nbytes` = its algorithmic bytes (tensor reads + writes)."""
+    if _timer is None:
+        L.call(name, *args)
+        return
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.call(name, *args)
+    e1.record()
+    _timer.add(kind, 0.0, e0, e1, kernels, float(nbytes))
 
 
 def _dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate):

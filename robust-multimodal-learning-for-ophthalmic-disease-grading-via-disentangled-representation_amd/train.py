@@ -185,6 +185,8 @@ def val(current_epoch, val_loader, model, best_acc, save_path=None):
         loss_sum += loss
         n_batches += 1
         n_seen += target.shape[0]
+    if hasattr(model, "raise_on_bad_labels"):
+        model.raise_on_bad_labels()
     acc = correct.item() / max(n_seen, 1)
     if acc > best_acc and save_path is not None:
         torch.save({"epoch": current_epoch, "state_dict": model.state_dict()}, save_path)

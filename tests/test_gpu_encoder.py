@@ -76,3 +76,32 @@ def test_encoders_tokens(edrl, dev):
     t, p = fe(xf.to(dev))
     check("fundus_tokens", t.cpu(), tr, 1e-4)
     check("fundus_pooled", p.cpu(), pr, 1e-4)
+
+
+@pytest.mark.parametrize("depth,in_ch", [(50, 3), (18, 1)])
+def test_trunk_recompute_block_outputs_bit_identical(edrl, dev, depth, in_ch):
+    """args.activation_recompute (ResNetTrunk.recompute_out, the mode BASELINE.json's B=64/GPU fp32 shapes need): the block
+    outputs rebuilt in backward come from the forward's own kernel on the same operands, so features, every parameter gradient
+    and the running statistics must be bit-identical to the run that kept them."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(4, 96, 96, in_ch if in_ch == 1 else 4, generator=g)
+    if in_ch == 3:
+        x[..., 3] = 0
+    gy = None
+    res = []
+    for rec in (False, True):
+        torch.manual_seed(0)
+        trunk = edrl.ResNetTrunk(depth, in_ch).to(dev).train()
+        trunk.recompute_out = rec
+        f = trunk(x.to(dev))
+        if gy is None:
+            gy = torch.randn(f.shape, generator=g).to(dev)
+        torch.cuda.reset_peak_memory_stats()
+        f.backward(gy)
+        res.append((f.detach().clone(), {n: p.grad.clone() for n, p in trunk.named_parameters()},
+                    {n: b.clone() for n, b in trunk.named_buffers()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), f"grad {n} differs under activation recompute"
+    for n in res[0][2]:
+        assert torch.equal(res[0][2][n], res[1][2][n]), f"buffer {n} differs under activation recompute"

@@ -109,8 +109,14 @@ def test_topk_selection_bit_exact_vs_reference_fixture(edrl, dev):
 def test_bad_label_raises_like_reference(edrl, dev):
     m = build(edrl, dev, 2, 5)
     x, x1, y, noise = O.make_head_inputs(6, 2, 9, 6)
+    m.check_labels(torch.tensor([0, 3], device=dev))       # default: recorded on the device, no host sync in the step ...
+    with pytest.raises(KeyError):
+        m.raise_on_bad_labels()                            # ... raised at the epoch boundary (train() / val() call this)
+    m.raise_on_bad_labels()                                # the flag is cleared once raised
+    m.strict_labels = True                                 # immediate mode: raises inside forward, like the reference
     with pytest.raises(KeyError):
         m.check_labels(torch.tensor([0, 3], device=dev))
+    m.strict_labels = "deferred"
     with pytest.raises(RuntimeError):
         m.forward_tokens(x[:1].to(dev), x1[:1].to(dev), y[:1].to(dev), to_dev(noise, dev))   # Q9: batch != args.batch_size
 
