@@ -49,6 +49,17 @@ def MK_MMD(source, target, kernel_mul=2.0, kernel_num=5):
     return torch.abs(XX + YY - XY - YX)
 
 
+def compute_kl_divergence(p, m):
+    """code/MMD.py:92-95: mean over rows of sum_k p*log(p/m)."""
+    return torch.sum(p * torch.log(p / m), dim=1).mean()
+
+
+def compute_js_divergence(p, q):
+    """code/MMD.py:76-90: 0.5*(KL(p||m) + KL(q||m)), m = 0.5*(p+q) (call site fusion_train.py:203-207, commented there)."""
+    m = 0.5 * (p + q)
+    return 0.5 * (compute_kl_divergence(p, m) + compute_kl_divergence(q, m))
+
+
 # ------------------------------------------------------------------ fusion_net.py head
 def off_diagonal(x):
     """fusion_net.py:544-548."""

@@ -127,6 +127,33 @@ def gen_mmd(ref_mmd):
     print("wrote mk_mmd.npz")
 
 
+def gen_divergences(ref_mmd):
+    """compute_js_divergence / compute_kl_divergence (code/MMD.py:76-95; the distillation call site fusion_train.py:203-207 is
+    commented out in the reference): softmax rows like the logits they were written for, plus a peaked pair."""
+    out = {}
+    cases = [(2, 2, 1.0), (8, 2, 3.0), (32, 4, 1.0), (5, 7, 8.0)]
+    for i, (B, C, temp) in enumerate(cases):
+        g = torch.Generator().manual_seed(300 + i)
+        p = torch.softmax(torch.randn(B, C, generator=g) * temp, 1).requires_grad_(True)
+        q = torch.softmax(torch.randn(B, C, generator=g) * temp, 1).requires_grad_(True)
+        js = ref_mmd.compute_js_divergence(p, q)
+        js.backward()
+        kl = ref_mmd.compute_kl_divergence(p.detach(), q.detach())
+        p2, q2 = p.detach().clone().requires_grad_(True), q.detach().clone().requires_grad_(True)
+        jo = O.compute_js_divergence(p2, q2)
+        jo.backward()
+        close(f"js{i}", jo.view(1), js.view(1), 1e-6)
+        close(f"js{i} dp", p2.grad, p.grad, 1e-5)
+        close(f"kl{i}", O.compute_kl_divergence(p.detach(), q.detach()).view(1), kl.view(1), 1e-6)
+        out.update({f"c{i}_B": B, f"c{i}_C": C, f"c{i}_temp": temp, f"c{i}_seed": 300 + i, f"c{i}_js": js.item(),
+                    f"c{i}_kl": kl.item(), f"c{i}_dp": p.grad.numpy(), f"c{i}_dq": q.grad.numpy()})
+    same = torch.softmax(torch.randn(4, 3, generator=torch.Generator().manual_seed(9)), 1)
+    assert ref_mmd.compute_js_divergence(same, same.clone()).item() == 0.0
+    out["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, "divergences.npz"), **out)
+    print("wrote divergences.npz")
+
+
 def gen_head(ref, ref_mmd, tag, B, N2, N3, seed):
     args = types.SimpleNamespace(mode="train&test", batch_size=B)
     torch.manual_seed(0)
@@ -195,6 +222,30 @@ def gen_head(ref, ref_mmd, tag, B, N2, N3, seed):
     out["adam_delta_norms"] = np.array([(ref_named[n].detach() - before[n]).double().norm().item() for n in names])
     np.savez_compressed(os.path.join(OUT, f"head_step_{tag}.npz"), **out)
     print(f"wrote head_step_{tag}.npz  (loss {loss.item():.6f}, mmd {loss_mdd.item():.6f})")
+
+
+def gen_rng_reference(ref, ref_mmd, B=4, N2=9, N3=6, seed=71, rng_seed=777):
+    """The reference run on the CPU with NO RNG interception: torch.manual_seed(rng_seed), then forward(view 1), forward(view 2).
+    Every random tensor (two Dropout masks and the proxy eps per EPRL, the two rand_like draws, PoE's discarded draw;
+    fusion_net.py:82-90,105-110,907,910,44-46) then comes from the global CPU generator in the reference's own order -- the
+    order MedFusion(rng="reference") must reproduce draw for draw (tests/test_gpu_head.py)."""
+    args = types.SimpleNamespace(mode="train&test", batch_size=B)
+    torch.manual_seed(0)
+    model = ref.MedFusion(2, 2, None, args)
+    missing, unexpected = model.load_state_dict(O.make_head_params(seed), strict=False)
+    assert not unexpected
+    model.train()
+    xa, x1a, y, _ = O.make_head_inputs(seed + 1, B, N2, N3)
+    xb, x1b, _, _ = O.make_head_inputs(seed + 2, B, N2, N3)
+    torch.manual_seed(rng_seed)
+    pred, loss, cf1 = model({0: xa, 1: x1a}, y, 0)
+    _, _, cf2 = model({0: xb, 1: x1b}, y, 0)
+    mmd = ref_mmd.MK_MMD(cf1, cf2)
+    after = torch.rand(4)                 # the generator state after both forwards, as 4 draws
+    np.savez_compressed(os.path.join(OUT, "head_rng_reference.npz"), B=B, N2=N2, N3=N3, seed=seed, rng_seed=rng_seed,
+                        pred=pred.detach().numpy(), loss=loss.item(), cf1=cf1.detach().numpy(), cf2=cf2.detach().numpy(),
+                        loss_MDD=mmd.item(), next_draws=after.numpy())
+    print(f"wrote head_rng_reference.npz (loss {loss.item():.6f}, mmd {mmd.item():.6f})")
 
 
 def gen_modules(ref):
@@ -293,8 +344,11 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     ref, ref_mmd = import_reference()
     gen_mmd(ref_mmd)
+    gen_divergences(ref_mmd)
     gen_modules(ref)
     gen_head(ref, ref_mmd, "tiny", 2, 9, 6, 21)
     gen_head(ref, ref_mmd, "refdims", 2, 144, 216, 31)
     gen_head(ref, ref_mmd, "b8", 8, 9, 6, 41)
+    gen_head(ref, ref_mmd, "refdims_b8", 8, 144, 216, 61)     # reference-native token counts at a batch where BatchNorm1d is well conditioned
     gen_eval(ref, "b4", 4, 51)
+    gen_rng_reference(ref, ref_mmd)

@@ -41,7 +41,11 @@ def _normal(shape, device, rng):
     return torch.randn(*shape, device=device)
 
 
-def _dropout_mask(shape, p, device):
+def _dropout_mask(shape, p, device, rng="device"):
+    if rng == "reference":
+        # what nn.Dropout does to a CPU tensor (at::dropout -> empty_like(x).bernoulli_(1-p).div_(1-p)), drawn from the global
+        # CPU generator at the same point of the draw order as the reference's F.dropout (fusion_net.py:82-90)
+        return torch.empty(shape, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p).to(device)
     return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
@@ -96,8 +100,8 @@ class EPRL(nn.Module):
         B, N, _ = x.shape
         dev = x.device
         if self.training:
-            m1 = noise["mask1"] if noise and "mask1" in noise else _dropout_mask((B, N, 2 * self.z_dim), 0.2, dev)
-            m2 = noise["mask2"] if noise and "mask2" in noise else _dropout_mask((B, N, 2 * self.z_dim), 0.2, dev)
+            m1 = noise["mask1"] if noise and "mask1" in noise else _dropout_mask((B, N, 2 * self.z_dim), 0.2, dev, self.rng)
+            m2 = noise["mask2"] if noise and "mask2" in noise else _dropout_mask((B, N, 2 * self.z_dim), 0.2, dev, self.rng)
         else:
             m1 = m2 = None
         h = ops.linear(x, e[0].weight, e[0].bias, relu=True, mask=m1)

@@ -93,9 +93,15 @@ def test_conv_bf16_fused_stats_and_casts(edrl, dev):
     check("bf16 fused rstd", outs[1].cpu(), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-4)
 
 
-@pytest.mark.parametrize("depth,in_ch,N,H", [(18, 1, 8, 96), (50, 3, 4, 128)])
-def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, monkeypatch):
+@pytest.mark.parametrize("depth,in_ch,N,H,dropped", [(18, 1, 8, 96, False), (50, 3, 4, 128, False),
+                                                     (18, 1, 8, 96, True), (50, 1, 4, 128, True)])
+def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, dropped, monkeypatch):
     """bf16 trunk (bf16 MFMA convs, bf16 activations/gradients, fp32 BN statistics) against the fp64 oracle.
+
+    dropped=True is config C4's missing-modality view (BASELINE.json configs[4]; data_harvard.py:333-334: the OCT volume of
+    the second view is all zeros): the stem conv output is identically 0, so the first BatchNorm sees EXACTLY zero variance
+    (rstd = eps^-1/2, output = relu(beta)) and every later one sees only the variance the zero padding of a constant image
+    creates -- through edrl_bn_apply_mx / edrl_bn_bwd_mx.  Random non-zero beta/gamma keep the pass non-trivial.
 
     (1) PER LAYER, tight: every conv->BN->(+res)->(ReLU) call the trunk makes is re-done by the oracle's storage-aware
         fp64 op (oracle/resnet_oracle.conv_bn_bf16_op) on the product's own bf16 inputs.  What is left is accumulation
@@ -116,8 +122,15 @@ def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, monkey
         for n, p in trunk.named_parameters():   # a gamma=1 random-init stack is chaotic at these tiny batch sizes
             if n.endswith(last_bn):
                 p.fill_(0.25)
+        if dropped:
+            gb = torch.Generator().manual_seed(7)
+            for n, p in trunk.named_parameters():
+                if n.endswith(".bias"):
+                    p.copy_((0.3 * torch.randn(p.shape, generator=gb) + 0.2).to(dev))
     g = torch.Generator().manual_seed(1)
     x = torch.rand(N, in_ch, H, H, generator=g)
+    if dropped:
+        x.zero_()
     sd_full = RO.trunk_state(trunk)
     sd_q = RO.trunk_state(trunk)
     f_full = RO.trunk_forward(x.double(), sd_full, trunk.kind, trunk.blocks)
@@ -136,9 +149,9 @@ def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, monkey
         r_raw, r_out, r_mean, r_var = RO.conv_bn_bf16_op(
             nchw(inp), w.detach().cpu().double(), bn["weight"].detach().cpu().double(),
             bn["bias"].detach().cpu().double(), stride, pad, relu, None if residual is None else nchw(residual))
-        worst["raw"] = max(worst["raw"], float((nchw(raw) - r_raw).norm() / r_raw.norm()))
+        worst["raw"] = max(worst["raw"], float((nchw(raw) - r_raw).norm() / r_raw.norm().clamp_min(1e-30)))
         worst["out"] = max(worst["out"], float((nchw(out) - r_out).norm() / r_out.norm().clamp_min(1e-30)))
-        worst["mean"] = max(worst["mean"], float((mean.cpu().double() - r_mean).abs().max() / r_mean.abs().max()))
+        worst["mean"] = max(worst["mean"], float((mean.cpu().double() - r_mean).abs().max() / r_mean.abs().max().clamp_min(1e-3)))
         worst["rstd"] = max(worst["rstd"], float((rstd.cpu().double() * torch.sqrt(r_var + 1e-5) - 1).abs().max()))
         worst["n"] += 1
         return res
@@ -154,7 +167,10 @@ def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, monkey
     print(f"[parity] bf16 trunk{depth}: {worst['n']} conv+BN layers checked per layer: raw {worst['raw']:.2e} "
           f"out {worst['out']:.2e} (tol 3e-4)  mean {worst['mean']:.2e} rstd {worst['rstd']:.2e} (tol 1e-5)")
     assert worst["n"] == n_convs
-    assert worst["raw"] < 3e-4 and worst["out"] < 3e-4 and worst["mean"] < 1e-5 and worst["rstd"] < 1e-5
+    # dropped view: a layer's input is (nearly) one value per channel, so a 1-ulp(bf16) rounding flip of that value moves
+    # thousands of equal elements together -- the norm-wise bound is looser there (1e-3; one bf16 ulp is 3.9e-3)
+    tol = 1e-3 if dropped else 3e-4
+    assert worst["raw"] < tol and worst["out"] < tol and worst["mean"] < 1e-5 and worst["rstd"] < 1e-5
 
     fh = f.permute(0, 3, 1, 2).cpu().double()
     rel = lambda a, b: float((a - b).norm() / b.norm())
@@ -179,7 +195,10 @@ def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, monkey
             margin, wn = m, f"{n}: product {cosf(got, ref):.4f} oracle {cosf(sd_q[n].grad.flatten(), ref):.4f}"
     print(f"[parity] bf16 trunk{depth} gradients: {n_checked} tensors, worst cosine margin vs storage-aware oracle "
           f"{margin:+.4f} ({wn})")
-    assert margin > -0.05 and n_checked > len(trunk.param_names) // 2
+    # dropped view: with (near-)zero-variance BatchNorm (rstd ~ eps^-1/2 amplification) hardly any gradient DIRECTION survives bf16
+    # storage even in the storage-aware fp64 oracle (its own cosine to the fp64 trunk is < 0.9 for most tensors), so only
+    # finiteness and the margin on the surviving tensors bind there
+    assert margin > -0.05 and n_checked > (0 if dropped else len(trunk.param_names) // 2)
 
 
 def test_bn_mx_kernels_vs_torch(edrl, dev):

@@ -66,3 +66,43 @@ def test_mk_mmd_full_size_properties(edrl, dev):
     ab, ba = edrl.MK_MMD(a, b).item(), edrl.MK_MMD(b, a).item()
     assert ab >= 0 and abs(ab - ba) <= 1e-6 * max(1.0, ab)
     assert edrl.MK_MMD(a, b).item() == ab, "deterministic"
+
+
+def test_c1_full_shape_step_finite_and_deterministic(edrl, dev):
+    """One full optimisation step at BASELINE.json configs[1] (C1: B=32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT,
+    fp32; fusion_train.py:189-224) -- the workload bench.py times, where the CPU oracle would take minutes.  Size-independent
+    properties: every loss term and every parameter gradient is finite, the predictions are valid class indices, BatchNorm
+    state advanced as the reference's would (2 encoder passes, DILR.bn 4 updates: quirk Q5), and a second run from the same
+    state and seeds reproduces the loss and the updated parameters BIT FOR BIT (ordered split-K / BN reductions, no atomics)."""
+    import copy
+    import types
+    args = types.SimpleNamespace(mode="train", batch_size=32, encoder_depth=50)
+    torch.manual_seed(0)
+    model = edrl.MedFusion(2, 2, None, args).to(dev).train()
+    state0 = copy.deepcopy(model.state_dict())
+    data, y = edrl.synthetic_batch(32, 224, 224, 32, device=dev, seed=1234)
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(state0)
+        opt = edrl.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        out = edrl.train_step(model, opt, data, y)
+        torch.cuda.synchronize()
+        runs.append((out["loss"].clone(), out["loss_MDD"].clone(), out["predicted"].clone(),
+                     {n: p.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    loss, mdd, pred, params, grads = runs[0]
+    assert torch.isfinite(loss) and torch.isfinite(mdd) and mdd.item() >= 0
+    assert pred.dtype == torch.int64 and int(pred.min()) >= 0 and int(pred.max()) <= 1
+    bad = [n for n, gr in grads.items() if not torch.isfinite(gr).all()]
+    assert not bad, f"non-finite gradients: {bad[:5]}"
+    assert len(grads) > 300                                        # both ResNet-50 trunks + the live head
+    sd = model.state_dict()
+    assert int(sd["DILR.bn1.num_batches_tracked"]) == 4 and int(sd["transformer_3DNet.trunk.bn1__num_batches_tracked"]) == 2
+    assert torch.equal(runs[1][0], loss) and torch.equal(runs[1][1], mdd) and torch.equal(runs[1][2], pred)
+    for n in params:
+        assert torch.equal(runs[1][3][n], params[n]), f"parameter {n} not reproduced bit for bit"
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f"[parity] C1 full-shape step: loss {loss.item():.6f}, loss_MDD {mdd.item():.3e}, {len(grads)} finite gradients, "
+          f"second run bit-identical, peak memory {peak:.1f} GiB")

@@ -32,7 +32,45 @@ def build(edrl, dev, B, seed):
     return m.to(dev).train()
 
 
-@pytest.mark.parametrize("tag", ["tiny", "b8", "refdims"])
+@pytest.mark.parametrize("tag", ["b8", "refdims_b8"])
+def test_head_step_vs_reference_fixture_fixed_tolerance(edrl, dev, tag):
+    """The north_star bound -- logits within 1e-4 relative of the reference -- with NO envelope term, on the fixtures whose
+    batch (8) keeps train-mode BatchNorm1d well conditioned: tokens (9, 6) and the reference-native (144, 216) of
+    fusion_net.py:885,157.  Values come from the real reference (oracle/gen_golden.py); losses 1e-4, features 1e-4, gradient
+    norms of every live tensor 1e-3, running statistics 1e-4, argmax bit-exact."""
+    z = np.load(os.path.join(GOLD, f"head_step_{tag}.npz"))
+    B, N2, N3, seed = int(z["B"]), int(z["N2"]), int(z["N3"]), int(z["seed"])
+    m = build(edrl, dev, B, seed)
+    xa, x1a, y, na = O.make_head_inputs(seed + 1, B, N2, N3)
+    xb, x1b, _, nb = O.make_head_inputs(seed + 2, B, N2, N3)
+    yd = y.to(dev)
+    pred, loss, cf1 = m.forward_tokens(xa.to(dev), x1a.to(dev), yd, to_dev(na, dev))
+    _, _, cf2 = m.forward_tokens(xb.to(dev), x1b.to(dev), yd, to_dev(nb, dev))
+    mmd = edrl.MK_MMD(cf1, cf2)
+    total = edrl.ops.scalar_mix([1.0, 1.0], [loss, mmd])
+    total.backward()
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    check(f"{tag}.pred(logits)", pred.cpu(), T(z["pred"]), 1e-4)
+    check(f"{tag}.cf1", cf1.cpu(), T(z["cf1"]), 1e-4)
+    check(f"{tag}.cf2", cf2.cpu(), T(z["cf2"]), 1e-4)
+    check(f"{tag}.loss", loss.cpu().view(1), T([float(z["loss"])]).float(), 1e-4)
+    check(f"{tag}.loss_MDD", mmd.cpu().view(1), T([float(z["loss_MDD"])]).float(), 1e-4)
+    check(f"{tag}.total", total.cpu().view(1), T([float(z["total"])]).float(), 1e-4)
+    assert torch.equal(edrl.ops.argmax_rows(pred).cpu(), T(z["predicted"])), "argmax must be bit exact"
+    check(f"{tag}.bn1.running_var", m.DILR.bn1.running_var.cpu(), T(z["bn1_running_var"]), 1e-4)
+    check(f"{tag}.bn2.running_mean", m.DILR.bn2.running_mean.cpu(), T(z["bn2_running_mean"]), 1e-4)
+    named = dict(m.named_parameters())
+    names = [str(n) for n in z["grad_names"]]
+    got = np.array([named[n].grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(got, z["grad_norms"], rtol=1e-3, atol=1e-8)
+    heads = np.stack([named[n].grad.flatten()[:16].cpu().numpy() if named[n].grad.numel() >= 16
+                      else np.pad(named[n].grad.flatten().cpu().numpy(), (0, 16 - named[n].grad.numel())) for n in names])
+    scale = np.maximum(np.abs(z["grad_head16"]).max(axis=1, keepdims=True), 1e-12)
+    # the first 16 elements of every gradient tensor, relative to that tensor's stored slice
+    assert (np.abs(heads - z["grad_head16"]) / scale).max() <= 2e-3
+
+
+@pytest.mark.parametrize("tag", ["tiny", "b8", "refdims", "refdims_b8"])
 def test_head_step_vs_reference_fixture_and_oracle(edrl, dev, tag):
     z = np.load(os.path.join(GOLD, f"head_step_{tag}.npz"))
     B, N2, N3, seed = int(z["B"]), int(z["N2"]), int(z["N3"]), int(z["seed"])
@@ -289,3 +327,32 @@ def test_training_loop_learns_separable_task(edrl, dev):
     assert last < 0.75 * first
     assert torch.equal(out["predicted"].cpu(), y)
     assert int(m.transformer_3DNet.trunk.get("bn1.num_batches_tracked")) == 80
+
+
+def test_rng_reference_mode_reproduces_the_reference_draw_order(edrl, dev):
+    """args.rng = "reference": dropout masks, proxy eps, guided-noise U and PoE's discarded draw are taken from the global
+    CPU generator in the reference's own call order (fusion_net.py:82-90,105-110,907,910,44-46), so a run seeded like the
+    reference sees the SAME random tensors.  Fixture head_rng_reference.npz = the real reference run on the CPU after
+    torch.manual_seed(777) with no RNG interception (oracle/gen_golden.py::gen_rng_reference): logits / features / losses must
+    match at 1e-4, and the generator must be left in the same state (next four draws bit-identical)."""
+    z = np.load(os.path.join(GOLD, "head_rng_reference.npz"))
+    B, N2, N3, seed, rng_seed = int(z["B"]), int(z["N2"]), int(z["N3"]), int(z["seed"]), int(z["rng_seed"])
+    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=18, rng="reference")
+    torch.manual_seed(0)
+    m = edrl.MedFusion(2, 2, None, args)
+    m.load_state_dict(O.make_head_params(seed), strict=False)
+    m = m.to(dev).train()
+    xa, x1a, y, _ = O.make_head_inputs(seed + 1, B, N2, N3)
+    xb, x1b, _, _ = O.make_head_inputs(seed + 2, B, N2, N3)
+    torch.manual_seed(rng_seed)
+    pred, loss, cf1 = m.forward_tokens(xa.to(dev), x1a.to(dev), y.to(dev))
+    _, _, cf2 = m.forward_tokens(xb.to(dev), x1b.to(dev), y.to(dev))
+    mmd = edrl.MK_MMD(cf1, cf2)
+    after = torch.rand(4)
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    assert torch.equal(after, T(z["next_draws"])), "the CPU generator was not consumed like the reference consumes it"
+    check("rng_reference.pred", pred.cpu(), T(z["pred"]), 1e-4)
+    check("rng_reference.cf1", cf1.cpu(), T(z["cf1"]), 1e-4)
+    check("rng_reference.cf2", cf2.cpu(), T(z["cf2"]), 1e-4)
+    check("rng_reference.loss", loss.cpu().view(1), T([float(z["loss"])]).float(), 1e-4)
+    check("rng_reference.loss_MDD", mmd.cpu().view(1), T([float(z["loss_MDD"])]).float(), 1e-4)

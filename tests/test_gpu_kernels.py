@@ -324,6 +324,32 @@ def test_bt_loss_and_bn1d(edrl, dev):
     check("bt_dy1", ag.grad.cpu(), a.grad, 5e-5); check("bt_dy2", bg.grad.cpu(), b.grad, 5e-5)
 
 
+def test_mk_mmd_vs_reference_fixture(edrl, dev):
+    """MK_MMD (code/MMD.py:46-74) against tests/golden/mk_mmd.npz, the numbers the REFERENCE produced (oracle/gen_golden.py):
+    all six cases, incl. unequal sample counts (5 vs 3) and the far-apart pair (shift 50, every kernel value underflows but
+    the self terms): loss 1e-5, gradients 1e-4 of each tensor's largest element; identical inputs give exactly 0."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mk_mmd.npz"))
+    for i in range(int(z["n_cases"])):
+        ns, nt, d, shift, seed = (int(z[f"c{i}_ns"]), int(z[f"c{i}_nt"]), int(z[f"c{i}_d"]), float(z[f"c{i}_shift"]),
+                                  int(z[f"c{i}_seed"]))
+        g = torch.Generator().manual_seed(seed)
+        s = torch.randn(ns, d, generator=g)
+        t = torch.randn(nt, d, generator=g) + shift
+        sg, tg = s.to(dev).requires_grad_(True), t.to(dev).requires_grad_(True)
+        lg = edrl.MK_MMD(sg, tg)
+        lg.backward()
+        ref = float(z[f"c{i}_loss"])
+        e = abs(lg.item() - ref) / max(abs(ref), 1e-30)
+        print(f"[parity] mk_mmd fixture case {i} (ns={ns}, nt={nt}, d={d}, shift={shift}): loss {lg.item():.7f} vs reference {ref:.7f} ({e:.1e})")
+        assert e <= 1e-5, (i, lg.item(), ref)
+        check(f"mmd_fixture{i}.ds", sg.grad.cpu(), torch.from_numpy(z[f"c{i}_ds"]), 1e-4)
+        check(f"mmd_fixture{i}.dt", tg.grad.cpu(), torch.from_numpy(z[f"c{i}_dt"]), 1e-4)
+    same = torch.randn(6, 40, generator=torch.Generator().manual_seed(7)).to(dev)
+    assert edrl.MK_MMD(same, same.clone()).item() == 0.0
+
+
 def test_mk_mmd(edrl, dev):
     g = torch.Generator().manual_seed(11)
     for (ns, nt, d, shift) in [(2, 2, 16, 0.5), (8, 8, 3072, 0.1), (32, 32, 3072, 0.02), (5, 3, 64, 3.0)]:

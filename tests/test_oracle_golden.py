@@ -74,7 +74,29 @@ def test_modules_golden():
     check("kl", O.KL_between_normals((mu, sg), (torch.zeros_like(mu), torch.ones_like(sg))), T(z["kl"]), 1e-6)
 
 
-@pytest.mark.parametrize("tag", ["tiny", "b8", "refdims"])
+def div_case(z, i):
+    B, C, temp, seed = int(z[f"c{i}_B"]), int(z[f"c{i}_C"]), float(z[f"c{i}_temp"]), int(z[f"c{i}_seed"])
+    g = torch.Generator().manual_seed(seed)
+    p = torch.softmax(torch.randn(B, C, generator=g) * temp, 1)
+    q = torch.softmax(torch.randn(B, C, generator=g) * temp, 1)
+    return p, q
+
+
+def test_js_kl_divergence_golden():
+    """compute_js_divergence / compute_kl_divergence (code/MMD.py:76-95) against the values the reference itself produced."""
+    z = np.load(os.path.join(GOLD, "divergences.npz"))
+    for i in range(int(z["n_cases"])):
+        p, q = div_case(z, i)
+        p.requires_grad_(True); q.requires_grad_(True)
+        js = O.compute_js_divergence(p, q)
+        js.backward()
+        assert abs(js.item() - float(z[f"c{i}_js"])) <= 1e-6 * max(1.0, abs(float(z[f"c{i}_js"])))
+        assert abs(O.compute_kl_divergence(p.detach(), q.detach()).item() - float(z[f"c{i}_kl"])) <= 1e-6 * max(1.0, abs(float(z[f"c{i}_kl"])))
+        check(f"js{i}.dp", p.grad, T(z[f"c{i}_dp"]), 1e-5)
+        check(f"js{i}.dq", q.grad, T(z[f"c{i}_dq"]), 1e-5)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "b8", "refdims", "refdims_b8"])
 def test_head_step_golden(tag):
     z = np.load(os.path.join(GOLD, f"head_step_{tag}.npz"))
     B, N2, N3, seed = int(z["B"]), int(z["N2"]), int(z["N3"]), int(z["seed"])
