@@ -75,10 +75,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        edrl_amd.dist.init_process_group(backend, device=dev)      # fail-fast: a failed / hung collective aborts the rank
 
     if a.config is None:
         a.config = "C1" if a.gpus == 1 else "C3"
@@ -99,7 +96,7 @@ def main():
     data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank, drop_oct_high=(a.config == "C4"))
 
     def step():
-        return edrl_amd.train_step(model, opt, data, y, grad_sync=sync.finish if sync else None)
+        return edrl_amd.train_step(model, opt, data, y, grad_sync=sync)
 
     def timed_region(steps, with_timer):
         timer = None

@@ -6,96 +6,138 @@ The reference has no distributed code (one dead all_reduce, fusion_net.py:686); 
 own DP layer.  Batch-coupled statistics (BatchNorm, bt_loss_cross, MK_MMD) stay per replica — the
 semantics DistributedDataParallel would give the reference — and `args.batch_size` is the per-GPU batch.
 
-Buckets are filled in reverse registration order (the order backward produces gradients); parameters
-that never receive a gradient (dead modules; EPRL.alpha/decoder_logits/mlp_*) are left out after the
-first step.  The exchange is a SUM followed by a 1/world scale, in place on the flat bucket.
+Layout.  The `.grad` of every exchanged parameter IS a view of its bucket's flat buffer (no gather / scatter
+copies): autograd accumulates into the bucket in place, the collective runs on the bucket in place (SUM, then
+x 1/world on the communication stream), and the optimiser reads the averaged gradients where they lie.  Buckets
+follow reverse registration order (the order backward produces gradients).  `GradSync.zero_grad()` replaces
+`optimizer.zero_grad()`: one fill per bucket, the views stay attached.
+
+Which parameters are exchanged is fixed at construction: `model.live_parameters()` when the model provides it
+(MedFusion does: its dead modules / eval-only parameters never receive gradients), otherwise every
+parameter that requires grad.  Hooks are armed from the very first step, so the first step overlaps like every other.
+A bucket whose parameters did not all report by `finish()` (a parameter unused in this step) is exchanged there with
+the zeros `zero_grad()` left in it.
 """
+import contextlib
+import datetime
+import os
+
 import torch
 import torch.distributed as dist
 
 
+def init_process_group(backend="nccl", device=None, timeout_s=180):
+    """torch.distributed initialisation with fail-fast error handling: a failed or hung RCCL collective aborts the
+    process (after `timeout_s`) instead of leaving the other ranks blocked in backward."""
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")      # tear the process down on a collective error
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (the only mode this host driver supports)
+    kw = dict(timeout=datetime.timedelta(seconds=timeout_s))
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+
+
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None):
+    def __init__(self, model, bucket_mb=64, process_group=None, params=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.params = [p for p in model.parameters() if p.requires_grad][::-1]
+        if params is None:
+            params = model.live_parameters() if hasattr(model, "live_parameters") else model.parameters()
+        self.params = [p for p in params if p.requires_grad][::-1]
         self.bucket_bytes = int(bucket_mb * (1 << 20))
-        self.buckets = None          # list of dicts {params, flat, ready, handle}
-        self.index = {}              # param -> (bucket id)
+        self.index = {}              # param -> bucket id
+        self.slot = {}               # param -> position inside its bucket
         self.comm_stream = None
+        self._sync = True
         self._hooks = []
-        self._step_active = False
-
-    # -- first step: no hooks yet; learn which parameters receive gradients, then build buckets
-    def _build(self):
-        live = [p for p in self.params if p.grad is not None]
-        self.buckets = []
-        cur, cur_bytes = [], 0
-        for p in live:
+        groups, cur, cur_bytes = [], [], 0
+        for p in self.params:
             cur.append(p)
             cur_bytes += p.numel() * 4
             if cur_bytes >= self.bucket_bytes:
-                self.buckets.append(cur); cur, cur_bytes = [], 0
+                groups.append(cur); cur, cur_bytes = [], 0
         if cur:
-            self.buckets.append(cur)
-        built = []
-        for bi, ps in enumerate(self.buckets):
+            groups.append(cur)
+        self.buckets = []
+        for bi, ps in enumerate(groups):
             n = sum(p.numel() for p in ps)
-            flat = torch.empty(n, device=ps[0].device, dtype=torch.float32)
+            flat = torch.zeros(n, device=ps[0].device, dtype=torch.float32)
             views, off = [], 0
             for p in ps:
-                views.append(flat[off:off + p.numel()].view_as(p)); off += p.numel()
+                v = flat[off:off + p.numel()].view_as(p)
+                views.append(v); off += p.numel()
                 self.index[p] = bi
-            built.append({"params": ps, "flat": flat, "views": views, "ready": 0, "handle": None, "event": None})
-        self.buckets = built
-        if live and live[0].is_cuda:
+                self.slot[p] = len(views) - 1
+                p.grad = v                                   # autograd accumulates into the bucket in place
+            self.buckets.append({"params": ps, "flat": flat, "views": views, "ready": 0, "launched": False, "handle": None})
+        if self.params and self.params[0].is_cuda:
             self.comm_stream = torch.cuda.Stream()
-        for p in live:
+        for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ---- step protocol: zero_grad() -> forward/backward (hooks launch full buckets) -> finish() -> optimizer.step()
+    def zero_grad(self):
+        """Zero every exchanged gradient (one fill per bucket; the `.grad` views stay attached) and re-arm the step."""
+        for b in self.buckets:
+            if b["handle"] is not None:                      # a step abandoned between backward and finish()
+                b["handle"].wait(); b["handle"] = None
+            b["flat"].zero_()
+            b["ready"], b["launched"] = 0, False
+            for p, v in zip(b["params"], b["views"]):
+                if p.grad is not v:                          # someone ran optimizer.zero_grad(set_to_none=True)
+                    p.grad = v
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only accumulate into the buckets; the exchange
+        happens in the first finish() outside it."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
 
     def _on_grad(self, p):
         b = self.buckets[self.index[p]]
+        v = b["views"][self.slot[p]]
+        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)                                  # the view was detached (set_to_none): put the gradient back
+            p.grad = v
+        if not self._sync:
+            return
         b["ready"] += 1
-        if b["ready"] == len(b["params"]):
+        if b["ready"] >= len(b["params"]) and not b["launched"]:
             self._launch(b)
 
     def _launch(self, b):
-        grads = [p.grad for p in b["params"]]
+        b["launched"] = True
+        if self.world == 1:
+            return
+        inv = 1.0 / self.world
         if self.comm_stream is not None:
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                torch._foreach_copy_(b["views"], grads)
-                if self.world > 1:
-                    b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        else:
-            torch._foreach_copy_(b["views"], grads)
-            if self.world > 1:
                 b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b["handle"].wait()                           # orders the scale after the collective ON the comm stream
+                b["handle"] = None
+                b["flat"].mul_(inv)
+        else:
+            dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
+            b["flat"].mul_(inv)
 
     def finish(self):
-        """Call after backward and before optimizer.step(): averages every gradient over the ranks."""
-        if self.buckets is None:
-            self._build()
-            for b in self.buckets:      # first step: nothing was launched from hooks
-                b["ready"] = len(b["params"])
-                self._launch(b)
-        inv = 1.0 / self.world
+        """Call after backward and before optimizer.step(): every gradient is the average over the ranks afterwards."""
         for b in self.buckets:
-            if b["ready"] != len(b["params"]):
-                raise RuntimeError("GradSync.finish(): a bucket is incomplete (a parameter stopped receiving gradients)")
-            if b["handle"] is not None:
-                b["handle"].wait()       # makes the current stream wait for the collective
-                b["handle"] = None
-            if self.comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.comm_stream)
-            if self.world > 1:
-                b["flat"].mul_(inv)
-            torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
-            b["ready"] = 0
+            if not b["launched"]:                            # a parameter of this bucket saw no gradient in this step
+                self._launch(b)
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for b in self.buckets:                               # re-arm: the next backward starts a new exchange even if the
+            b["ready"], b["launched"] = 0, False             # caller zeroes gradients some other way than zero_grad()
 
     def total_bytes(self):
-        return sum(b["flat"].numel() * 4 for b in (self.buckets or []))
+        return sum(b["flat"].numel() * 4 for b in self.buckets)
 
 
 def broadcast_parameters(model, src=0, group=None):

@@ -361,6 +361,14 @@ class MedFusion(nn.Module):
             loss = self.compute_loss_train(loss1, kl_f, kl_o, pl_f, pl_o, loss_DILR)
         return pred, loss, combine_features
 
+    _EVAL_ONLY = (".alpha", ".decoder_logits.", ".mlp_2d.", ".mlp_3d.")
+
+    def live_parameters(self):
+        """The parameters that receive a gradient in a training step, in registration order: everything except EPRL's
+        eval-branch parameters (alpha, decoder_logits, mlp_2d, mlp_3d; fusion_net.py:152-218) -- what the DP gradient
+        buckets are built from before the first backward (dist.GradSync; SURVEY.md App. C lists the same set)."""
+        return [p for n, p in self.named_parameters() if not any(k in n + "." for k in self._EVAL_ONLY)]
+
     def trunks(self):
         return tuple(t for t in (self.transformer_2DNet.trunk, self.transformer_3DNet.trunk)
                      if hasattr(t, "begin_scratch_running"))

@@ -111,9 +111,12 @@ class DevicePrefetcher:
 
 def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None, grad_sync=None):
     """One iteration of the loop body at fusion_train.py:176-225. Returns device tensors, no host sync.
-    `grad_sync` (optional): called after backward, before optimizer.step (DP gradient all-reduce)."""
+    `grad_sync` (optional): a dist.GradSync (its zero_grad() keeps the gradients attached to the DP buckets, its finish()
+    runs after backward and before optimizer.step), or a bare callable invoked after backward."""
     data1, data2 = data
     optimizer.zero_grad()
+    if hasattr(grad_sync, "zero_grad"):
+        grad_sync.zero_grad()          # re-attaches the bucket views as .grad (zeroed) after the set_to_none above
     if _VIEW_STREAM and target.is_cuda and model.training:
         # The two views' encoder passes are independent (they meet in MK_MMD): the second one runs on a side stream so
         # that its HBM-bound BatchNorm kernels overlap the first one's MFMA-bound convolutions and vice versa; autograd
@@ -148,7 +151,7 @@ def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None
     predicted = ops.argmax_rows(pred)
     total.backward()
     if grad_sync is not None:
-        grad_sync()
+        (grad_sync.finish if hasattr(grad_sync, "finish") else grad_sync)()
     optimizer.step()
     return {"loss": total.detach(), "loss_MDD": loss_MDD.detach(), "pred": pred.detach(), "predicted": predicted}
 

@@ -1,6 +1,7 @@
 """CPU, world_size 2, gloo: the DP gradient exchange (GradSync) — bucketing, hook-driven launches after the
-first step, dead parameters skipped, two forwards sharing weights, and N-rank averaged gradients equal to the
-single-process gradients on the concatenated batch for batch-decoupled losses."""
+first step on, gradients living in the flat buckets, dead parameters skipped, two forwards sharing weights, a detached-view
+(set_to_none) step, a gradient-accumulation (no_sync) step, and N-rank averaged gradients equal to the single-process
+gradients on the concatenated batch for batch-decoupled losses."""
 import os
 import socket
 import sys
@@ -43,17 +44,30 @@ def _worker(rank, world, port, q):
     torch.manual_seed(0)
     net = Net()
     edrl_amd.broadcast_parameters(net)
-    sync = edrl_amd.GradSync(net, bucket_mb=0.001)     # tiny buckets -> several collectives
+    live = [p for n, p in net.named_parameters() if not n.startswith("dead")]   # (MedFusion supplies live_parameters() itself)
+    sync = edrl_amd.GradSync(net, bucket_mb=0.001, params=live)     # tiny buckets -> several collectives
+    views = {n: p.grad.data_ptr() for n, p in net.named_parameters() if p.grad is not None}
     g = torch.Generator().manual_seed(5)
-    X1, X2 = torch.randn(3, 8, 16, generator=g), torch.randn(3, 8, 16, generator=g)   # 3 steps, global batch 8
+    X1, X2 = torch.randn(4, 8, 16, generator=g), torch.randn(4, 8, 16, generator=g)   # 4 steps, global batch 8
     per = 8 // world
     res = []
-    for step in range(3):
-        net.zero_grad()
+    for step in range(4):
+        if step == 2:
+            net.zero_grad()          # set_to_none=True detaches the bucket views: the hooks must put the gradients back
+        else:
+            sync.zero_grad()
         x1, x2 = X1[step, rank * per:(rank + 1) * per], X2[step, rank * per:(rank + 1) * per]
-        _loss(net, x1, x2).backward()
+        if step == 3:                # gradient accumulation: two half micro-batches, exchange only once
+            h = per // 2
+            with sync.no_sync():
+                (_loss(net, x1[:h], x2[:h]) * 0.5).backward()
+            (_loss(net, x1[h:], x2[h:]) * 0.5).backward()
+        else:
+            _loss(net, x1, x2).backward()
         sync.finish()
         res.append({n: p.grad.numpy().copy() for n, p in net.named_parameters() if p.grad is not None})
+        assert all(p.grad.data_ptr() == views[n] for n, p in net.named_parameters() if p.grad is not None), \
+            "gradients must live in the flat buckets (no gather/scatter copies)"
     q.put((rank, res, len(sync.buckets), sync.total_bytes()))
     dist.destroy_process_group()
 
@@ -73,12 +87,12 @@ def test_gradsync_world2_matches_single_process():
     torch.manual_seed(0)
     net = Net()
     g = torch.Generator().manual_seed(5)
-    X1, X2 = torch.randn(3, 8, 16, generator=g), torch.randn(3, 8, 16, generator=g)
+    X1, X2 = torch.randn(4, 8, 16, generator=g), torch.randn(4, 8, 16, generator=g)
     live_bytes = sum(p.numel() * 4 for n, p in net.named_parameters() if not n.startswith("dead"))
     for rank, res, nb, nbytes in outs:
         assert nb > 1, "expected several buckets"
         assert nbytes == live_bytes, "dead parameters must not be exchanged"
-        for step in range(3):
+        for step in range(4):
             net.zero_grad()
             _loss(net, X1[step], X2[step]).backward()
             assert "dead.weight" not in res[step]

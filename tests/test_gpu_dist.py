@@ -1,0 +1,103 @@
+"""Two data-parallel ranks driving the REAL MedFusion step, rehearsed on one MI355X: both processes use
+cuda:0 and exchange over gloo (host-staged; RCCL needs one GPU per rank, which the driver's 8-GPU run provides).  Checks the
+DP contract of §8(e): after GradSync.finish() every gradient equals the MEAN of the two ranks' single-rank gradients, where the
+batch-coupled terms (BatchNorm statistics, bt_loss_cross, MK_MMD, EPRL's expand(batch_size)) are per replica; gradients live
+in the flat buckets; EPRL's eval-only parameters are not exchanged; the optimiser then steps both ranks identically."""
+import os
+import socket
+import sys
+import types
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _grads_of(edrl_amd, model, data, y, seed, sync=None):
+    """forward(low) -> forward(high) -> MK_MMD -> backward (fusion_train.py:189-213) with the RNG seeded per data shard."""
+    torch.manual_seed(seed); torch.cuda.manual_seed(seed)
+    if sync is not None:
+        sync.zero_grad()
+    else:
+        model.zero_grad()
+    pred, loss, cf1 = model(data[0], y, 0)
+    _, _, cf2 = model(data[1], y, 0)
+    total = edrl_amd.ops.scalar_mix([1.0, 1.0], [loss, edrl_amd.MK_MMD(cf1, cf2)])
+    total.backward()
+    if sync is not None:
+        sync.finish()
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch.distributed as dist
+        import edrl_amd
+        torch.cuda.set_device(0)
+        edrl_amd.dist.init_process_group("gloo", timeout_s=120)
+        dev = torch.device("cuda:0")
+        args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
+        torch.manual_seed(0)
+        model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
+        edrl_amd.broadcast_parameters(model)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        shards = [edrl_amd.synthetic_batch(2, 64, 64, 4, device=dev, seed=1234, rank=r) for r in range(world)]
+        single = []
+        for r in range(world):                     # what each rank would compute alone (running statistics reset in between)
+            model.load_state_dict(state0)
+            single.append(_grads_of(edrl_amd, model, shards[r][0], shards[r][1], 1000 + r))
+        model.load_state_dict(state0)
+        sync = edrl_amd.GradSync(model, bucket_mb=8)
+        bucket_ptrs = {n: p.grad.data_ptr() for n, p in model.named_parameters() if p.grad is not None}
+        opt = edrl_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-6)
+        got = _grads_of(edrl_amd, model, shards[rank][0], shards[rank][1], 1000 + rank, sync)
+        worst, wn = 0.0, ""
+        for n, g in got.items():
+            want = sum(s[n] for s in single) / world
+            e = ((g - want).abs().max() / want.abs().max().clamp_min(1e-20)).item()
+            if e > worst:
+                worst, wn = e, n
+        in_bucket = all(p.grad.data_ptr() == bucket_ptrs[n] for n, p in model.named_parameters() if n in bucket_ptrs)
+        dead = [n for n, p in model.named_parameters() if p.grad is None]
+        opt.step()
+        torch.cuda.synchronize()
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().item()
+        q.put((rank, worst, wn, in_bucket, len(got), dead, chk, len(sync.buckets)))
+        dist.destroy_process_group()
+    except Exception as e:                            # surface the failure to the parent instead of a silent timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_dp2_medfusion_step_one_gpu_gloo():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for o in outs:
+        assert o[1] != "error", o[2]
+    outs.sort(key=lambda o: o[0])
+    for rank, worst, wn, in_bucket, n_live, dead, chk, nb in outs:
+        print(f"[parity] DP2 rank {rank}: {n_live} exchanged gradients in {nb} buckets, worst |avg - mean(single)| rel {worst:.2e} ({wn})")
+        assert worst <= 1e-5, (rank, worst, wn)
+        assert in_bucket, "gradients must be views of the flat buckets"
+        assert n_live > 150
+        assert all(any(k in n + "." for k in (".alpha", ".decoder_logits.", ".mlp_2d.", ".mlp_3d.")) for n in dead), dead
+    assert outs[0][6] == outs[1][6], "both ranks must hold identical parameters after the step"
