@@ -8,11 +8,13 @@ Compute lives in libedrl_hip.so (hand-written HIP, C-ABI in include/edrl_hip.h);
 package never builds or falls back: a missing library raises on first use.
 """
 from . import _lib, ops
+from . import custom_ops          # registers torch.ops.edrl.* (torch.library schemas over the same C-ABI launchers)
 from .mmd import MK_MMD, compute_js_divergence, compute_kl_divergence
 from .medfusion import MedFusion, EPRL, PoE, DILR, AttentionModel, off_diagonal
 from .encoders import ResNetTrunk, FundusEncoder, OCTSliceEncoder
 from .encoders3d import ResNet3DTrunk, OCTVolumeEncoder
 from .train import train_step, train, val, synthetic_batch, device_twin_views, set_view_overlap, DevicePrefetcher
+from . import dist
 from .dist import GradSync, broadcast_parameters
 from .optim import FusedAdam
 

@@ -734,6 +734,8 @@ class ResNetTrunk(nn.Module):
         self.param_names = [n for n, _ in self.named_parameters()]
         self._capture = None
         self._wt_cache = {}
+        self._register_state_dict_hook(self._save_hook)
+        self._register_load_state_dict_pre_hook(self._load_pre_hook)
         # True: do not keep the residual blocks' outputs for backward (rebuilt there from the raw conv outputs: one extra
         # elementwise pass per block, -30 % activation memory) -- what lets BASELINE.json's B=64/GPU fp32 shapes fit 288 GB
         self.recompute_out = os.environ.get("EDRL_RECOMPUTE_OUT", "0") == "1"
@@ -799,6 +801,9 @@ class ResNetTrunk(nn.Module):
         run = [self.get(n + s) for n in self._bn_names for s in (".running_mean", ".running_var")]
         torch._foreach_mul_(run, 0.9)
         torch._foreach_add_(run, [t for n in self._bn_names for t in bufs[n]])
+        # the concurrent pass did not touch num_batches_tracked (bump_batches_tracked): its increment is applied here, in
+        # order on the joining stream, so the counter advances by exactly 2 per step whatever the streams' interleaving
+        torch._foreach_add_([self.get(n + ".num_batches_tracked") for n in self._bn_names], 1)
 
     def wgrad_stream(self):
         s = getattr(self, "_wgrad_stream", None)
@@ -807,7 +812,39 @@ class ResNetTrunk(nn.Module):
         return s
 
     def bump_batches_tracked(self):
+        if getattr(self, "_scratch_running", None) is not None:
+            return          # a pass running beside another one on a second stream: counted in merge_scratch_running()
         torch._foreach_add_([self.get(n + ".num_batches_tracked") for n in self._bn_names], 1)
+
+    # ---- checkpoint key / layout compatibility: state_dict() exposes torchvision-style names ("layer1.0.conv1.weight",
+    # "bn1.running_mean") and conv weights in torch's [Co,Ci,KH,KW] layout without the stem's zero padding channel, so that
+    # NCHW ResNet checkpoints load and saved ones are readable elsewhere; internally parameters stay [Co,KH,KW,Ci] under
+    # attribute-safe names ('.' -> '__').  Checkpoints written with the internal names / layout still load.
+    def _save_hook(self, module, sd, prefix, local_meta):
+        for key in [k for k in sd if k.startswith(prefix) and "__" in k[len(prefix):]]:
+            name = key[len(prefix):].replace("__", ".")
+            t = sd.pop(key)
+            if t.dim() == 4:
+                t = t.permute(0, 3, 1, 2)
+                if name == "conv1.weight" and self.in_ch_padded != self.in_ch:
+                    t = t[:, :self.in_ch]
+                t = t.contiguous()
+            sd[prefix + name] = t
+        return sd
+
+    def _load_pre_hook(self, sd, prefix, local_meta, strict, missing, unexpected, errors):
+        own = {n.replace("__", "."): n for n in list(self._parameters) + list(self._buffers)}
+        for name, internal in own.items():
+            key = prefix + name
+            if key not in sd or name == internal:
+                continue
+            t = sd.pop(key)
+            if t.dim() == 4:                                  # [Co,Ci,KH,KW] -> [Co,KH,KW,Ci] (+ the stem's zero channel)
+                t = t.permute(0, 2, 3, 1)
+                if name == "conv1.weight" and t.shape[-1] == self.in_ch and self.in_ch_padded != self.in_ch:
+                    t = torch.cat([t, t.new_zeros(*t.shape[:-1], self.in_ch_padded - self.in_ch)], dim=-1)
+                t = t.contiguous()
+            sd[prefix + internal] = t
 
     def forward(self, x_nhwc):
         if not self.training:

@@ -66,3 +66,60 @@ def test_resnet_trunk_shapes(edrl):
     assert tuple(t50.get("conv1.weight").shape) == (64, 7, 7, 4) and float(t50.get("conv1.weight")[..., 3].abs().max()) == 0
     assert tuple(t18.get("conv1.weight").shape) == (64, 7, 7, 1)
     assert len(t50.blocks) == 16 and len(t18.blocks) == 8
+
+
+def test_encoder_state_dict_uses_torchvision_names_and_nchw_layout():
+    """Checkpoint compatibility of the build-owned encoders (the `{'epoch','state_dict'}` file of fusion_train.py:332): keys are
+    dotted torchvision names, conv weights are [Co,Ci,KH,KW] without the stem's zero padding channel; a round trip is exact, an
+    NCHW ResNet dict loads, and a checkpoint written with the internal names / [Co,KH,KW,Ci] layout (round 1) still loads."""
+    import torch
+    import edrl_amd
+    torch.manual_seed(0)
+    t = edrl_amd.ResNetTrunk(18, 3)
+    sd = t.state_dict()
+    assert "layer2.0.downsample.0.weight" in sd and "bn1.running_mean" in sd and not any("__" in k for k in sd)
+    assert tuple(sd["conv1.weight"].shape) == (64, 3, 7, 7) and tuple(sd["layer1.0.conv1.weight"].shape) == (64, 64, 3, 3)
+    assert torch.equal(sd["layer1.0.conv1.weight"], t.get("layer1.0.conv1.weight").detach().permute(0, 3, 1, 2))
+    torch.manual_seed(1)
+    t2 = edrl_amd.ResNetTrunk(18, 3)
+    res = t2.load_state_dict(sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (n, a), (_, b) in zip(t.named_parameters(), t2.named_parameters()):
+        assert torch.equal(a, b), n
+    assert tuple(t2.get("conv1.weight").shape) == (64, 7, 7, 4) and float(t2.get("conv1.weight")[..., 3].abs().max()) == 0
+    # a torchvision-style dict built by hand (NCHW conv weights)
+    tv = {k: (torch.randn_like(v) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    t2.load_state_dict(tv)
+    assert torch.equal(t2.get("layer3.1.conv2.weight"), tv["layer3.1.conv2.weight"].permute(0, 2, 3, 1))
+    # internal-format checkpoint (attribute names with '__', [Co,KH,KW,Ci]) as round 1 wrote them
+    old = {n: v.detach().clone() for n, v in list(t._parameters.items()) + list(t._buffers.items())}
+    t3 = edrl_amd.ResNetTrunk(18, 3)
+    res = t3.load_state_dict(old)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(t3.get("layer4.1.conv1.weight"), t.get("layer4.1.conv1.weight"))
+    # through the full model: encoder keys sit under transformer_2DNet.trunk.* / transformer_3DNet.trunk.*
+    import types
+    m = edrl_amd.MedFusion(2, 2, None, types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18))
+    keys = m.state_dict().keys()
+    assert "transformer_3DNet.trunk.layer1.0.bn1.num_batches_tracked" in keys and "transformer_2DNet.trunk.conv1.weight" in keys
+    m.load_state_dict(m.state_dict())
+
+
+def test_torch_library_ops_are_registered_with_schemas():
+    """the operators exist as torch.library custom ops (`torch.ops.edrl.*`) on top of the C-ABI; no CPU kernel is
+    registered, so CPU tensors are rejected instead of silently computed somewhere else."""
+    import pytest
+    import torch
+    import edrl_amd
+    from edrl_amd_pkg import custom_ops
+    for name in custom_ops.REGISTERED:
+        op = getattr(torch.ops.edrl, name)
+        schema = str(op.default._schema)
+        assert schema.startswith(f"edrl::{name}("), schema
+    assert "Int stride, SymInt pad" in str(torch.ops.edrl.conv2d_nhwc.default._schema)
+    assert "Tensor? bias" in str(torch.ops.edrl.gemm_bias_act.default._schema)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.edrl.conv2d_nhwc(torch.zeros(1, 4, 4, 16), torch.zeros(16, 1, 1, 16), 1, 0)
+    # fake (meta) kernels give shapes without touching a device
+    y = torch.ops.edrl.conv2d_nhwc(torch.zeros(2, 8, 8, 16, device="meta"), torch.zeros(32, 3, 3, 16, device="meta"), 2, 1)
+    assert tuple(y.shape) == (2, 4, 4, 32)

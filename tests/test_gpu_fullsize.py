@@ -99,7 +99,7 @@ def test_c1_full_shape_step_finite_and_deterministic(edrl, dev):
     assert not bad, f"non-finite gradients: {bad[:5]}"
     assert len(grads) > 300                                        # both ResNet-50 trunks + the live head
     sd = model.state_dict()
-    assert int(sd["DILR.bn1.num_batches_tracked"]) == 4 and int(sd["transformer_3DNet.trunk.bn1__num_batches_tracked"]) == 2
+    assert int(sd["DILR.bn1.num_batches_tracked"]) == 4 and int(sd["transformer_3DNet.trunk.bn1.num_batches_tracked"]) == 2
     assert torch.equal(runs[1][0], loss) and torch.equal(runs[1][1], mdd) and torch.equal(runs[1][2], pred)
     for n in params:
         assert torch.equal(runs[1][3][n], params[n]), f"parameter {n} not reproduced bit for bit"

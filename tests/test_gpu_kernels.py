@@ -464,3 +464,52 @@ def test_stem_space_to_depth_conv_equals_7x7_conv(edrl, dev, C, N, H, W):
     check(f"stem_s2d_wgrad[C={C}]", dw.cpu().permute(0, 3, 1, 2), wd.grad, 2e-5)
     w8 = ops.stem_weight_fold(wh)
     assert torch.equal(ops.stem_weight_fold(w8, inverse=True), wh)      # fold / unfold are exact copies
+
+
+def test_torch_library_ops_match_the_function_path(edrl, dev):
+    """`torch.ops.edrl.*` (torch.library registration) run the same launchers as the ops.py autograd Functions:
+    values and gradients must be bit-identical, and torch.library.opcheck accepts schema / fake kernel / autograd registration."""
+    ops = edrl.ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 9, 7, 32, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(48, 3, 3, 32, generator=g) * 0.1).to(dev).requires_grad_(True)
+    y = torch.ops.edrl.conv2d_nhwc(x, w, 2, 1)
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(gy)
+    assert torch.equal(y.detach(), ops.conv2d_fwd(x.detach(), w.detach(), stride=2, pad=1))
+    assert torch.equal(x.grad, ops.conv2d_dgrad(gy, ops.permute_weight(w.detach()), tuple(x.shape), 2, 1))
+    assert torch.equal(w.grad, ops.conv2d_wgrad(gy, x.detach(), tuple(w.shape), 2, 1))
+    # Linear + ReLU + dropout mask
+    xl = torch.randn(5, 6, 64, generator=g).to(dev)
+    wl = (torch.randn(40, 64, generator=g) * 0.1).to(dev)
+    bl = torch.randn(40, generator=g).to(dev)
+    ml = (torch.rand(5, 6, 40, generator=g) > 0.2).float().div(0.8).to(dev)
+    outs = []
+    for fn in (lambda a, b, c: torch.ops.edrl.gemm_bias_act(a, b, c, ml, True), lambda a, b, c: ops.linear(a, b, c, relu=True, mask=ml)):
+        a, b, c = xl.clone().requires_grad_(True), wl.clone().requires_grad_(True), bl.clone().requires_grad_(True)
+        o = fn(a, b, c)
+        o.backward(torch.ones_like(o))
+        outs.append((o.detach(), a.grad, b.grad, c.grad))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    # MK-MMD and label-smoothed CE
+    s, t = torch.randn(8, 96, generator=g).to(dev), (torch.randn(8, 96, generator=g) + 0.3).to(dev)
+    res = []
+    for fn in (edrl.custom_ops.mk_mmd if hasattr(edrl, "custom_ops") else None, edrl.MK_MMD):
+        if fn is None:
+            continue
+        a, b = s.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        l = fn(a, b); l.backward()
+        res.append((l.detach(), a.grad, b.grad))
+    assert len(res) == 2 and all(torch.equal(u, v) for u, v in zip(*res))
+    pred = torch.randn(6, 2, generator=g).to(dev).requires_grad_(True)
+    yl = torch.randint(0, 2, (6,), generator=g).to(dev)
+    l1 = torch.ops.edrl.smooth_ce(pred, yl, 0.1); l1.backward()
+    p2 = pred.detach().clone().requires_grad_(True)
+    l2 = ops.smooth_ce(p2, yl, 0.1); l2.backward()
+    assert torch.equal(l1.detach(), l2.detach()) and torch.equal(pred.grad, p2.grad)
+    # registration sanity (schema, fake tensors, autograd wiring)
+    torch.library.opcheck(torch.ops.edrl.conv2d_nhwc.default, (x.detach().requires_grad_(True), w.detach().requires_grad_(True), 2, 1),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    torch.library.opcheck(torch.ops.edrl.smooth_ce.default, (pred.detach().requires_grad_(True), yl, 0.1),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
