@@ -7,12 +7,15 @@ from util import check
 pytestmark = pytest.mark.gpu
 
 
-# Seeds: a ReLU input within ~1e-6 of zero can round to different sides in fp32 and fp64; such a flip changes ONE
-# activation gradient by O(1) and every upstream weight gradient by ~1e-3..1e-2 (measured: ~1 flip per 10^6 ReLU
-# elements).  That is a property of comparing any fp32 pipeline with an fp64 one (the fp32 CPU oracle flips as often), not
-# of the kernels, so each case uses an input seed whose draw has no boundary element; the fp32-oracle envelope guards it.
+# End-to-end trunk against the fp64 oracle.  The BINDING gradient parity lives in tests/test_gpu_layerwise.py (every unit
+# re-done in fp64 on the product's own operands at a fixed 1e-4; whole-network gradients with the discrete decisions pinned at a
+# fixed 3e-4).  An UNPINNED fp32-vs-fp64 gradient comparison of a 50-layer train-mode-BatchNorm network cannot bind tightly: a
+# ReLU pre-activation within round-off of zero takes different sides in the two precisions and moves every upstream gradient by
+# 1e-3..1e-2 (demonstrated, with counts, by test_trunk_grads_pinned_decisions).  So here: forward at a FIXED tolerance, running
+# statistics, and a fixed direction bound (cosine >= 0.999 per parameter tensor) that a wrong kernel anywhere upstream breaks.
 @pytest.mark.parametrize("depth,in_ch,N,H,W,seed", [(18, 1, 3, 64, 64, 1), (50, 3, 8, 128, 128, 1),
-                                                     (18, 1, 8, 99, 85, 5),      # odd, non-square: direct 7x7 stem, ragged tiles
+                                                     (18, 1, 8, 99, 85, 1),      # odd, non-square: direct 7x7 stem, ragged tiles (round 1's red case)
+                                                     (18, 1, 8, 99, 85, 5),
                                                      (34, 3, 3, 96, 70, 1)])     # ResNet-34, non-square
 def test_trunk_fwd_bwd(edrl, dev, depth, in_ch, N, H, W, seed):
     from oracle import resnet_oracle as RO
@@ -29,26 +32,21 @@ def test_trunk_fwd_bwd(edrl, dev, depth, in_ch, N, H, W, seed):
     xh = torch.zeros(N, H, W, cp)
     xh[..., :in_ch] = x.permute(0, 2, 3, 1)
     f = trunk(xh.to(dev))
-    # yardstick: the fp32 round-off envelope of the same network, i.e. the oracle run in fp32 vs fp64
-    with torch.no_grad():
-        f32 = RO.trunk_forward(x, RO.trunk_state(trunk, dtype=torch.float32, requires_grad=False), trunk.kind, trunk.blocks)
-    env = ((f32.double() - f_ref).abs().max() / f_ref.abs().max()).item()
-    print(f"[parity] trunk{depth}: fp32-CPU-oracle vs fp64 envelope {env:.3e}")
-    check(f"trunk{depth}_fwd", f.permute(0, 3, 1, 2).cpu(), f_ref, max(1e-4, 3 * env))
+    check(f"trunk{depth}_fwd", f.permute(0, 3, 1, 2).cpu(), f_ref, 3e-4)        # fixed; measured 5e-6 (R18) .. 1.2e-4 (R50)
     f.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
-    # gradient yardstick: the same oracle in fp32 (autograd on the CPU) against fp64
-    sd32 = RO.trunk_state(trunk, dtype=torch.float32)
-    RO.trunk_forward(x, sd32, trunk.kind, trunk.blocks).backward(gy)
-    worst, worst_env = 0.0, 0.0
+    worst_cos, worst_fro, wn = 1.0, 0.0, ""
     for n, p in trunk.named_parameters():
-        ref = sd[n].grad
-        scale = ref.abs().max().clamp_min(1e-20)
-        e = ((p.grad.cpu().double() - ref).abs().max() / scale).item()
-        env_g = ((sd32[n].grad.double() - ref).abs().max() / scale).item()
-        worst, worst_env = max(worst, e), max(worst_env, env_g)
-        assert e < max(2e-3, 10 * env_g), f"grad {n}: rel err {e:.3e} (fp32 envelope {env_g:.3e})"
-    print(f"[parity] trunk{depth} fp32-CPU-oracle gradient envelope {worst_env:.3e}")
-    print(f"[parity] trunk{depth} worst param-grad rel err {worst:.3e}")
+        ref = sd[n].grad.flatten()
+        got = p.grad.cpu().double().flatten()
+        assert torch.isfinite(got).all(), n
+        cos = float((got @ ref) / (got.norm() * ref.norm()).clamp_min(1e-30))
+        fro = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+        if cos < worst_cos:
+            worst_cos, wn = cos, n
+        worst_fro = max(worst_fro, fro)
+        assert cos >= 0.999, f"grad {n}: cosine {cos:.6f} to the fp64 oracle"
+    print(f"[parity] trunk{depth} N={N} {H}x{W} seed {seed}: worst param-grad cosine {worst_cos:.6f} ({wn}), worst relative "
+          f"Frobenius {worst_fro:.2e} (unpinned fp32-vs-fp64; binding checks: test_gpu_layerwise.py)")
     check("bn1.running_mean", trunk.get("bn1.running_mean").cpu(), sd["bn1.running_mean"], 1e-5)
     last = trunk.blocks[-1]["name"] + (".bn3" if trunk.kind == "bottleneck" else ".bn2")
     check("last.running_var", trunk.get(last + ".running_var").cpu(), sd[last + ".running_var"], 1e-4)

@@ -95,7 +95,7 @@ def test_head_step_vs_reference_fixture_and_oracle(edrl, dev, tag):
     from util import relerr
     env = max(relerr(r32["cf1"], res["cf1"]), relerr(r32["cf2"], res["cf2"]), relerr(r32["pred"], res["pred"]))
     print(f"[parity] {tag}: fp32-CPU-oracle vs fp64 envelope (cf/pred) {env:.3e}")
-    tol = max(1e-4, 5 * env)
+    tol = max(1e-4, min(5 * env, 1e-3))      # the envelope may relax the bound for the B=2 fixtures, never beyond a fixed 1e-3
     check(f"{tag}.pred(logits)", pred.cpu(), T(z["pred"]), tol)
     check(f"{tag}.cf1", cf1.cpu(), T(z["cf1"]), tol)
     check(f"{tag}.cf2", cf2.cpu(), T(z["cf2"]), tol)
@@ -110,7 +110,7 @@ def test_head_step_vs_reference_fixture_and_oracle(edrl, dev, tag):
     names = [str(n) for n in z["grad_names"]]
     got = np.array([named[n].grad.double().norm().item() for n in names])
     genv = max(abs(r32["grads"][n].double().norm().item() / max(res["grads"][n].norm().item(), 1e-30) - 1) for n in names)
-    np.testing.assert_allclose(got, z["grad_norms"], rtol=max(2e-3, 5 * genv), atol=1e-8)
+    np.testing.assert_allclose(got, z["grad_norms"], rtol=max(2e-3, min(5 * genv, 1e-2)), atol=1e-8)
     check(f"{tag}.pred_vs_fp64", pred.cpu(), res["pred"], tol)
     worst = 0.0
     for n in names:
@@ -119,7 +119,7 @@ def test_head_step_vs_reference_fixture_and_oracle(edrl, dev, tag):
         e = ((g - r).abs().max() / sc).item()
         e32 = ((r32["grads"][n].double() - r).abs().max() / sc).item()
         worst = max(worst, e)
-        assert e < max(2e-3, 5 * e32), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
+        assert e < max(2e-3, min(5 * e32, 1e-2)), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
     print(f"[parity] {tag}: worst elementwise grad rel err vs fp64 oracle {worst:.3e}")
     # dead parameters stay without gradient, exactly as in the reference
     for n in ("EPRL_fundus.alpha", "EPRL_fundus.decoder_logits.weight", "EPRL_oct.mlp_3d.1.weight"):
@@ -181,7 +181,7 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high):
     from util import relerr
     env = max(relerr(r32["pred"], ref["pred"]), relerr(r32["total"].view(1), ref["total"].view(1)))
     print(f"[parity] full step: fp32-CPU-oracle vs fp64 envelope (pred/loss) {env:.3e}")
-    tol = max(1e-4, 5 * env)
+    tol = max(1e-4, min(5 * env, 1e-3))
     opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
     ddev = ([t.to(dev) for t in data[0]], [t.to(dev) for t in data[1]])
@@ -204,7 +204,7 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high):
         e = ((g - r).abs().max() / sc).item()
         e32 = ((r32["grads"][n].double() - r).abs().max() / sc).item()
         worst = max(worst, e); nchk += 1
-        assert e < max(5e-3, 10 * e32), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
+        assert e < max(5e-3, min(10 * e32, 2e-2)), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
     print(f"[parity] full step: {nchk} gradient tensors, worst rel err vs fp64 oracle {worst:.3e}")
     # Adam moved every parameter that has a gradient
     moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in m.named_parameters() if p.grad is not None)

@@ -77,7 +77,7 @@ def test_resnet3d_trunk_fwd_bwd_vs_oracle(edrl, dev):
     f = trunk(x.view(2, 16, 64, 64, 1).to(dev))
     assert tuple(f.shape) == (2, 1, 2, 2, 512)
     env = relerr(f32, f64)
-    check("trunk3d_fwd", f.detach().cpu().permute(0, 4, 1, 2, 3), f64.detach(), max(1e-4, 5 * env))
+    check("trunk3d_fwd", f.detach().cpu().permute(0, 4, 1, 2, 3), f64.detach(), max(1e-4, min(5 * env, 1e-3)))
     f.backward(gy.permute(0, 2, 3, 4, 1).contiguous().to(dev))
     worst = 0.0
     for n, p in trunk.named_parameters():
@@ -86,7 +86,7 @@ def test_resnet3d_trunk_fwd_bwd_vs_oracle(edrl, dev):
         e = float((p.grad.cpu().double() - r).abs().max() / sc)
         e32 = float((sd32[n].grad.double() - r).abs().max() / sc)
         worst = max(worst, e)
-        assert e < max(5e-3, 10 * e32), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
+        assert e < max(5e-3, min(10 * e32, 2e-2)), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
     print(f"[parity] trunk3d: fwd envelope {env:.2e}, worst gradient rel err {worst:.3e}")
     assert int(trunk.bn1.num_batches_tracked) == 1
     check("trunk3d bn1.running_mean", trunk.bn1.running_mean.cpu(), sd64["bn1.running_mean"], 1e-5)
