@@ -630,6 +630,36 @@ __global__ __launch_bounds__(256) void sum_axis1_kernel(const float* __restrict_
     out[i] = s * scale;
   }
 }
+// float4 columns, the L rows of one `a` spread over RL = TPB/CG row lanes (fixed order -> deterministic): the per-image global
+// average pool (A = B*S images, L = 49) and the bias gradients (A = 1, L = all rows) no longer walk L serially per column.
+template <int TPB>
+__global__ __launch_bounds__(TPB) void sum_axis1_v4_kernel(const float* __restrict__ in, float* __restrict__ out, long A,
+                                                           int L, int D, float scale) {
+  __shared__ f32x4 sh[TPB];
+  const int C4 = D >> 2;
+  const int CG = C4 < 64 ? C4 : 64;
+  const int RL = TPB / CG;
+  const int tid = threadIdx.x, cg = tid % CG, rl = tid / CG;
+  const int c4 = blockIdx.x * CG + cg;
+  const long a = blockIdx.y;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (c4 < C4 && rl < RL) {
+    const float* p = in + (a * L) * D + (long)c4 * 4;
+    int l = rl;
+    for (; l + RL < L; l += 2 * RL) {
+      s0 += *reinterpret_cast<const f32x4*>(p + (long)l * D);
+      s1 += *reinterpret_cast<const f32x4*>(p + (long)(l + RL) * D);
+    }
+    if (l < L) s0 += *reinterpret_cast<const f32x4*>(p + (long)l * D);
+  }
+  sh[tid] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && c4 < C4) {
+    f32x4 t = sh[cg];
+    for (int q = 1; q < RL; ++q) t += sh[q * CG + cg];
+    *reinterpret_cast<f32x4*>(out + a * D + (long)c4 * 4) = t * scale;
+  }
+}
 // out [A][L][D] (+)= scale * in [A][D]
 __global__ __launch_bounds__(256) void bcast_axis1_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           long A, int L, int D, float scale, int accumulate) {
@@ -1070,7 +1100,16 @@ int edrl_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int 
 // out[a][d] = scale * sum_l in[a][l][d]   (global avg-pool, token mean)
 int edrl_sum_axis1_f32(const float* in, float* out, long A, int L, int D, float scale, hipStream_t st) {
   if (A <= 0 || L <= 0 || D <= 0) return EDRL_EINVAL;
-  hipLaunchKernelGGL(sum_axis1_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, in, out, A, L, D, scale);
+  if ((D & 3) == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0 && A <= 65535) {
+    const int C4 = D >> 2, CG = C4 < 64 ? C4 : 64;
+    const dim3 grid(edrl_cdiv(C4, CG), (unsigned)A);
+    if ((long)grid.x * grid.y < 512 && L >= 64)      // few blocks, long columns (bias gradients): 16 row lanes per column group
+      hipLaunchKernelGGL(sum_axis1_v4_kernel<1024>, grid, dim3(1024), 0, st, in, out, A, L, D, scale);
+    else
+      hipLaunchKernelGGL(sum_axis1_v4_kernel<256>, grid, dim3(256), 0, st, in, out, A, L, D, scale);
+  } else {
+    hipLaunchKernelGGL(sum_axis1_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, in, out, A, L, D, scale);
+  }
   EDRL_LAUNCH_CHECK();
   return 0;
 }

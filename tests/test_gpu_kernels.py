@@ -513,3 +513,14 @@ def test_torch_library_ops_match_the_function_path(edrl, dev):
                           test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
     torch.library.opcheck(torch.ops.edrl.smooth_ce.default, (pred.detach().requires_grad_(True), yl, 0.1),
                           test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+
+
+@pytest.mark.parametrize("A,Ln,D", [(33, 49, 2048), (1, 1568, 1024), (1, 70000, 64), (4, 7, 12), (2, 5, 6), (1, 3, 2048)])
+def test_sum_axis1_paths(edrl, dev, A, Ln, D):
+    """Global average pool (per-image, L = 49) / bias-gradient column sums (A = 1, long L) / scalar fallback (D % 4 != 0):
+    vs fp64, and run-to-run deterministic (fixed-order row-lane reduction)."""
+    g = torch.Generator().manual_seed(A + Ln + D)
+    x = torch.randn(A, Ln, D, generator=g).to(dev)
+    y = edrl.ops.sum_axis1(x, 0.5)
+    check(f"sum_axis1[{A},{Ln},{D}]", y.cpu(), 0.5 * x.double().cpu().sum(1), 2e-6 * max(1.0, Ln ** 0.5))
+    assert torch.equal(y, edrl.ops.sum_axis1(x, 0.5))
