@@ -173,6 +173,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
                     "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+                    "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"]),
+                    "algorithmic_flop_per_byte": round(dom["flops"] / dom["bytes"], 2) if dom.get("bytes") else None,
                     "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
                     "launch_unit": "kernel launches as rocprofv3 counts them (a stride-2 data-gradient call issues one kernel "
                                    "per non-empty parity class; the HIP events bracket the call); rocprofv3's conv_gather_* rows are these "
@@ -185,11 +187,13 @@ def main():
             res["kernels"] = {}
             for k, v in ks.items():
                 e = {"launches": v["launches"], "calls": v["calls"], "ms_total": round(v["ms"], 3)}
-                if "GBps" in v:      # HBM-bound passes: algorithmic bytes / HIP-event time against the 8 TB/s HBM3E spec
+                if "GBps" in v and v["flops"] == 0:      # HBM-bound passes: algorithmic bytes / HIP-event time against the 8 TB/s HBM3E spec
                     e.update(bound="hbm", GBps=round(v["GBps"], 1), frac_of_8TBps=round(v["GBps"] / 8000.0, 4),
                              algorithmic_bytes=v["bytes"])
                 else:
                     e.update(bound="mfma", tflops=round(v["tflops"], 3))
+                    if v.get("bytes"):
+                        e.update(algorithmic_GBps=round(v["GBps"], 1), algorithmic_bytes=v["bytes"])
                 res["kernels"][k] = e
         if "roofline" in res:
             # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py);

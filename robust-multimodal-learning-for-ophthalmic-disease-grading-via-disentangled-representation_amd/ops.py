@@ -75,9 +75,10 @@ def set_timer(t):
     _timer = t
 
 
-def _launch_timed(kind, flops, name, *args, kernels=1):
+def _launch_timed(kind, flops, name, *args, kernels=1, nbytes=0.0):
     """`kernels`: MFMA kernels the C-ABI call issues (a strided data gradient issues one per non-empty parity class),
-    so that the timer's launch count is the one rocprofv3 sees."""
+    so that the timer's launch count is the one rocprofv3 sees.  `nbytes`: algorithmic HBM bytes of the call (every operand
+    tensor read once, every result written once; weights included)."""
     if _timer is None:
         L.call(name, *args)
         return
@@ -85,7 +86,7 @@ def _launch_timed(kind, flops, name, *args, kernels=1):
     e0.record()
     L.call(name, *args)
     e1.record()
-    _timer.add(kind, flops, e0, e1, kernels)
+    _timer.add(kind, flops, e0, e1, kernels, nbytes)
 
 
 def call_timed_bytes(kind, nbytes, name, *args, kernels=1):
@@ -139,7 +140,8 @@ def conv2d_fwd(x, w, bias=None, mul=None, stride=1, pad=0, relu=False, out=None,
         out = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.float32)
     flags = (FLAG_RELU if relu else 0) | (FLAG_ACCUM if accumulate else 0)
     _launch_timed("conv_gather", alg_flops or 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_f32", P(x), P(w), P(bias),
-                  P(mul), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Ci, Co, Co, flags)
+                  P(mul), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Ci, Co, Co, flags,
+                  nbytes=4.0 * (x.numel() + w.numel() + out.numel() * (2 if accumulate else 1)))
     return out
 
 
@@ -154,7 +156,8 @@ def conv2d_fwd_stats(x, w, stat_shift, stride=1, pad=0):
     chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
     part = torch.empty((chunks, 3, Co), device=x.device, dtype=torch.float32)
     _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_stats_f32", P(x), P(w), P(out),
-                  P(stat_shift), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)
+                  P(stat_shift), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad,
+                  nbytes=4.0 * (x.numel() + w.numel() + out.numel()))
     return out, part, chunks
 
 
@@ -222,7 +225,8 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=False):
         out = torch.empty((N, Hi, Wi, Ci), device=dy.device, dtype=torch.float32)
     _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_f32", P(dy), P(wt),
                   P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, FLAG_ACCUM if accumulate else 0,
-                  kernels=_dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate))
+                  kernels=_dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate),
+                  nbytes=4.0 * (dy.numel() + wt.numel() + out.numel() * (2 if accumulate else 1)))
     return out
 
 
@@ -236,7 +240,8 @@ def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False, al
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
     ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
     _launch_timed("conv_wgrad", alg_flops or 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_f32", P(dy), P(x),
-                  P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, 1 if accumulate else 0)
+                  P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, 1 if accumulate else 0,
+                  nbytes=4.0 * (dy.numel() + x.numel() + out.numel()))
     return out
 
 
@@ -258,7 +263,8 @@ def conv2d_fwd_bnin_stats(x_raw, in_fcoef, w, stride=1, pad=0):
     chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
     part = torch.empty((chunks, 3, Co), device=x_raw.device, dtype=torch.float32)
     _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_bnin_stats_f32", P(x_raw),
-                  P(in_fcoef), P(w), P(out), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)
+                  P(in_fcoef), P(w), P(out), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad,
+                  nbytes=4.0 * (x_raw.numel() + w.numel() + out.numel()))
     return out, part, chunks
 
 
@@ -281,7 +287,9 @@ def conv2d_dgrad_bn(g, yraw, bcoef, wt, x_shape, stride=1, pad=0, out=None, accu
     kernels = _dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate and ep is None)
     _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bn_f32", P(g), P(yraw), P(bcoef),
                   P(wt), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0, P(ep_raw),
-                  P(ep_mask), P(ep_fcoef), 1 if ep_relu else 0, P(part), nbytes, kernels=kernels)
+                  P(ep_mask), P(ep_fcoef), 1 if ep_relu else 0, P(part), nbytes, kernels=kernels,
+                  nbytes=4.0 * (2 * g.numel() + wt.numel() + out.numel() * (2 if accumulate else 1) +
+                                (out.numel() if ep is not None else 0)))
     return out if ep is None else (out, part, chunks)
 
 
@@ -294,7 +302,8 @@ def conv2d_wgrad_bn(g, yraw, bcoef, x, x_fcoef, w_shape, stride=1, pad=0):
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
     ws = torch.empty(nbytes // 4, device=g.device, dtype=torch.float32)
     _launch_timed("conv_wgrad", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_bn_f32", P(g), P(yraw), P(bcoef),
-                  P(x), P(x_fcoef), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 0)
+                  P(x), P(x_fcoef), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 0,
+                  nbytes=4.0 * (2 * g.numel() + x.numel() + out.numel()))
     return out
 
 
