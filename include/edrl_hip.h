@@ -169,6 +169,24 @@ int edrl_bn_bwd_finalize_partials_f32(const float* part, long nchunks, int plane
                                       const float* fcoef, float* dgamma, float* dbeta, float* bcoef, double* group_ws,
                                       size_t group_ws_bytes, hipStream_t stream);
 
+/* bf16 counterparts of the fused-BatchNorm entry points (conv_bf16.hip / bn_pool.hip): bf16 tensors, fp32 coefficient arrays
+ * fcoef [5][C] / bcoef [4][C] and fp32 partial sums; same contracts as the _f32 versions above.  Ci % 32 == 0, Co % 32 == 0. */
+int edrl_conv2d_fused_ok_bf16(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad);
+int edrl_conv2d_nhwc_fwd_bnin_stats_bf16(const void* x, const float* in_fcoef, const void* w, void* y, float* stat_part,
+                                         size_t stat_part_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                         int KW, int stride, int pad, hipStream_t stream);
+int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g, const void* yraw, const float* bcoef, const void* wt, void* dx, int N,
+                                   int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                   int flags, const void* ep_raw, const unsigned char* ep_mask, const float* ep_fcoef,
+                                   int ep_relu, float* ep_part, size_t ep_part_bytes, hipStream_t stream);
+int edrl_conv2d_nhwc_wgrad_bn_bf16(const void* g, const void* yraw, const float* bcoef, const void* x, const float* x_fcoef,
+                                   float* dw, float* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int Ci, int Ho,
+                                   int Wo, int Co, int KH, int KW, int stride, int pad, int accumulate, hipStream_t stream);
+int edrl_bn_apply_res_bf16(const void* x, const float* fcoef, const void* residual, const float* res_fcoef, void* out,
+                           unsigned char* relu_mask, long M, int C, int relu, hipStream_t stream);
+int edrl_bn_bwd_reduce_bf16(const void* dout, const unsigned char* relu_mask, const void* x, const float* fcoef, void* g_out,
+                            float* part, size_t part_bytes, long M, int C, hipStream_t stream);
+
 /* Mixed-precision BatchNorm apply / backward and max-pool of the bf16 (C2) trunk: raw_bf16 / act_bf16 give the storage type
  * (0 fp32, 1 bf16) of the raw conv output (+ its gradient) and of the activated tensors (+ their gradients); statistics,
  * affine and reductions stay fp32/fp64.  Dense rows. */

@@ -751,7 +751,8 @@ __device__ __forceinline__ void ld8f(const float* p, float* o) {
 __global__ __launch_bounds__(256) void bn_apply_h8_kernel(const __bf16* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const __bf16* __restrict__ residual, __bf16* __restrict__ out,
-                                                          unsigned char* __restrict__ mask_out, long M, int C, int relu) {
+                                                          unsigned char* __restrict__ mask_out, long M, int C, int relu,
+                                                          const float* __restrict__ res_coef = nullptr) {
   const int C8 = C >> 3;
   const long total = M * C8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -765,6 +766,12 @@ __global__ __launch_bounds__(256) void bn_apply_h8_kernel(const __bf16* __restri
     if (residual) {
       float rv[8];
       ld8h(residual + r * C + c, rv);
+      if (res_coef) {      // the residual is the raw downsample-branch output: its BatchNorm is applied here
+        float rm[8], rsc[8], rsf[8];
+        ld8f(res_coef + c, rm); ld8f(res_coef + 2 * (long)C + c, rsc); ld8f(res_coef + 3 * (long)C + c, rsf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = (rv[e] - rm[e]) * rsc[e] + rsf[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rv[e];
     }
@@ -817,7 +824,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const __bf16* __re
 __global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dout,
                                                           const unsigned char* __restrict__ rmask,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          long M, int C, float* __restrict__ part) {
+                                                          long M, int C, float* __restrict__ part,
+                                                          __bf16* __restrict__ gout = nullptr) {
   __shared__ float sh[256 * 16];
   const int C8 = C >> 3;
   const int CG = C8 < 64 ? C8 : 64;      // 8-channel groups per block (C8 is a power of two or the block tail is idle)
@@ -840,6 +848,7 @@ __global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float ge = (!masked || ((mb >> (e < 4 ? e : e + 4)) & 1)) ? g[e] : 0.f;
+        g[e] = ge;
         s0[e] += ge;
         s1[e] += ge * ((xv[e] - mu[e]) * rs[e]);
       }
@@ -855,7 +864,10 @@ __global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restri
         mb[u] = rmask ? *reinterpret_cast<const unsigned short*>(rmask + (rr * C8 + (c >> 3)) * 2) : 0;
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc(xv[u], gv[u], mb[u], rmask != nullptr);
+      for (int u = 0; u < U; ++u) {
+        acc(xv[u], gv[u], mb[u], rmask != nullptr);
+        if (gout) st8h(gout + (r + (long)u * RL) * C + c, gv[u]);
+      }
     }
     for (; r < row1; r += RL) {
       float xv[8], gv[8];
@@ -863,6 +875,7 @@ __global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restri
       ld8h(dout + r * C + c, gv);
       const int mb = rmask ? *reinterpret_cast<const unsigned short*>(rmask + (r * C8 + (c >> 3)) * 2) : 0;
       acc(xv, gv, mb, rmask != nullptr);
+      if (gout) st8h(gout + r * C + c, gv);
     }
   }
   float* my = sh + tid * 16;
@@ -1203,6 +1216,28 @@ int edrl_bn_bwd_mx(const void* dout, int act_bf16, const unsigned char* relu_mas
                                          dbeta, (float*)dx, (__bf16*)dres, M, C, workspace, st);
   return EDRL_EINVAL;
 }
+// bf16 counterparts of edrl_bn_apply_res_f32 / edrl_bn_bwd_reduce_f32 (bf16 raw tensors, activations and gradients; fp32
+// coefficients and sums).  C % 8 == 0.
+int edrl_bn_apply_res_bf16(const void* x, const float* fcoef, const void* residual, const float* res_fcoef, void* out,
+                           unsigned char* relu_mask, long M, int C, int relu, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 7) || !x || !fcoef || !out) return EDRL_EINVAL;
+  hipLaunchKernelGGL(bn_apply_h8_kernel, dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)x, fcoef,
+                     fcoef + 2 * (long)C, fcoef + 3 * (long)C, (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, relu,
+                     res_fcoef);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_bn_bwd_reduce_bf16(const void* dout, const unsigned char* relu_mask, const void* x, const float* fcoef, void* g_out,
+                            float* part, size_t part_bytes, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 7) || !dout || !x || !fcoef || !part) return EDRL_EINVAL;
+  if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
+  const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL(colstat1_h8_kernel, dim3(chunks, edrl_cdiv(C, 512)), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)dout,
+                     relu_mask, fcoef, fcoef + (long)C, M, C, part, (__bf16*)g_out);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
 int edrl_maxpool3x3s2_fwd_bf16(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t st) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;

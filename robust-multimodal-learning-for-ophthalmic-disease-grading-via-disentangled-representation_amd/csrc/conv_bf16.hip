@@ -10,6 +10,7 @@
 // the weight gradient stay on the fp32 kernels (conv_gemm.hip) in round 1.
 #include "edrl_common.h"
 #include <stdlib.h>
+#include <string.h>
 #include "conv_geom.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -22,10 +23,20 @@ typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
 
 // BUF: operand loads through buffer descriptors exactly as in conv_gemm.hip's fp32 kernel (masked rows / taps are an
 // out-of-range offset the hardware zero-fills; one add per staged piece and tile).
-template <int BN, bool DGRAD, bool BUF = false>
+//
+// Fused BatchNorm (BUF only; conv_geom.h GatherFuse), the bf16 counterpart of conv_gemm.hip's ATR / EPI variants -- next to the
+// bf16 MFMA the VALU is a separate pipe, so the transforms are nearly free and the kernel stays HBM-bound on most layers:
+//   ATR 1: the gathered operand is a RAW (bf16) conv output; bf16(relu(x*scale + shift2)) is formed while the tile is staged.
+//   ATR 2: the gathered operand is d_raw = bf16(A*g + nK2*x + C2) from the masked gradient g (src) and the raw output x (src2).
+//   EPI 1: the computed tile is the gradient of a BatchNorm(+ReLU) output: masked (sign bytes or decision re-derived from the
+//          raw tensor), stored as bf16, and (sum g, sum g*x) of the UNROUNDED fp32 values go to ep_part.
+//   MASK : padding taps / masked rows must read as exactly 0 after the transform (false for 1x1 / pad-0 layers).
+template <int BN, bool DGRAD, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true>
 __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* __restrict__ src,
                                                                   const __bf16* __restrict__ wm,
-                                                                  __bf16* __restrict__ dst, GatherGeom g, int tiles_n) {
+                                                                  __bf16* __restrict__ dst, GatherGeom g, int tiles_n,
+                                                                  GatherFuse F) {
+  static_assert(ATR == 0 || BUF, "operand transforms ride on the buffer-descriptor path");
   constexpr int BM = 128;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
   long tapoff = 0;
   constexpr unsigned OOB = 0x80000000u;
   unsigned aoff[A_LD], boff[B_LD], wrow2[B_LD];
-  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  __amdgpu_buffer_rsrc_t rs_a, rs_b, rs_a2, rs_p;
   int n_first = 0, cb = 0;
   if constexpr (BUF) {
     const int ohw = g.OHs * g.OWs;
@@ -82,6 +93,10 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
     const unsigned a_bytes = (unsigned)(((long)(n_last - n_first + 1) * g.SH * g.SW - 1) * g.ld_src * 2 + (long)g.SC * 2);
     rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
     rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, (int)((long)g.NC * g.Kfull * 2), 0x00020000);
+    if constexpr (ATR == 2)
+      rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const __bf16*)F.src2 + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
+    if constexpr (ATR != 0)
+      rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)F.acoef, 0, 5 * g.SC * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int n = n0 + r0 + 64 * i;
@@ -146,11 +161,28 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
   bf16x8 zero8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
+  bf16x8 a_st2[ATR == 2 ? A_LD : 1];
+  f32x4 tp[ATR == 2 ? 6 : 4];            // per-channel parameters of the staged K tile (8 channels cb+k8 .. +7, two float4 per row)
   auto load_tile = [&]() {
     if constexpr (BUF) {
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i)
+      for (int i = 0; i < A_LD; ++i) {
         a_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)aoff[i], 0, 0));
+        if constexpr (ATR == 2) a_st2[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, (int)aoff[i], 0, 0));
+        if constexpr (ATR != 0 && MASK) a_ok[i] = (int)aoff[i] >= 0;
+      }
+      if constexpr (ATR != 0) {
+        const int po = (cb + k8) * 4;      // fp32 coefficient rows; channels cb+k8 .. +7 (< SC always)
+        constexpr int R0 = ATR == 1 ? 2 : 0, R1 = ATR == 1 ? 4 : 1;      // ATR 1: scale, shift2 | ATR 2: A, nK2, (C2 = row 2)
+        tp[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, R0 * g.SC * 4, 0));
+        tp[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po + 16, R0 * g.SC * 4, 0));
+        tp[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, R1 * g.SC * 4, 0));
+        tp[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po + 16, R1 * g.SC * 4, 0));
+        if constexpr (ATR == 2) {
+          tp[4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po, 2 * g.SC * 4, 0));
+          tp[5] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, po + 16, 2 * g.SC * 4, 0));
+        }
+      }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i)
         b_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)boff[i], 0, 0));
@@ -168,6 +200,23 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
       const bool ok = kvalid && wrow[i] >= 0;
       b_ok[i] = ok;
       b_st[i] = *reinterpret_cast<const bf16x8*>(wm + (ok ? wrow[i] + tapoff + c : 0));
+    }
+  };
+  auto transform_tile = [&]() {
+    if constexpr (ATR != 0) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (float)a_st[i][e];
+          float v;
+          if constexpr (ATR == 1) v = fmaxf(__builtin_fmaf(x, tp[e >> 2][e & 3], tp[2 + (e >> 2)][e & 3]), 0.f);
+          else v = __builtin_fmaf(tp[2 + (e >> 2)][e & 3], (float)a_st2[i][e], __builtin_fmaf(tp[e >> 2][e & 3], x, tp[4 + (e >> 2)][e & 3]));
+          o[e] = (__bf16)v;
+        }
+        if constexpr (MASK) a_st[i] = a_ok[i] ? o : zero8; else a_st[i] = o;
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -191,6 +240,7 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
 
   const int KT = (g.Ktot + HBK - 1) / HBK;
   load_tile();
+  transform_tile();
   store_tile(0);
   __syncthreads();
 
@@ -216,13 +266,14 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    transform_tile();
     store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // ---- vector epilogue through LDS (fp32 staging): lane owns 4 consecutive channels of one pixel -> 8-byte bf16 store
   const bool accum = g.flags & GF_ACCUM;
-  const bool stats = (g.flags & GF_STATS) != 0;
+  const bool stats = EPI == 0 && (g.flags & GF_STATS) != 0;
   constexpr int SLD = WN + 4;
   constexpr int C4 = WN / 4;
   constexpr int RPP2 = 64 / C4;
@@ -230,6 +281,13 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
   const int srow = lane / C4, sc4 = lane % C4;
   const int n = n0 + wn0 + sc4 * 4;
   f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 e_scale = {0.f, 0.f, 0.f, 0.f}, e_shift2 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == 1) {
+    if (n < g.NC && !F.ep_mask) {
+      e_scale = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + n);
+      e_shift2 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + n);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -262,6 +320,22 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
         }
+        if constexpr (EPI == 1) {
+          const bf16x4 xb = *reinterpret_cast<const bf16x4*>((const __bf16*)F.ep_x + pix * F.ld_ep + n);
+          f32x4 xr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xr[e] = (float)xb[e];
+          if (F.ep_mask) {
+            const int mb = F.ep_mask[pix * (long)(g.NC >> 2) + (n >> 2)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (mb >> e) & 1 ? v[e] : 0.f;
+          } else if (g.flags & GF_EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xr[e], e_scale[e], e_shift2[e]) > 0.f ? v[e] : 0.f;
+          }
+          st0 += v;
+          st1 = __builtin_elementwise_fma(v, xr, st1);
+        }
         bf16x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = (__bf16)v[e];
@@ -269,6 +343,32 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int o = 32; o >= C4; o >>= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
+    }
+    float* red = smem + 4 * 32 * SLD;          // [wave][2][WN]
+    if (srow == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(wave * 2 + 0) * WN + sc4 * 4 + e] = st0[e];
+        red[(wave * 2 + 1) * WN + sc4 * 4 + e] = st1[e];
+      }
+    }
+    __syncthreads();
+    if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
+      float* pp = F.ep_part + ((long)F.ep_chunk0 + tile_m) * 2 * g.NC;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = sc4 * 4 + e;
+        pp[n + e] = st0[e] + red[((wave + 2) * 2 + 0) * WN + cc];
+        pp[g.NC + n + e] = st1[e] + red[((wave + 2) * 2 + 1) * WN + cc];
+      }
+    }
+    return;
   }
   if (stats) {
 #pragma unroll
@@ -303,8 +403,9 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
   }
 }
 
-template <int BN, bool DGRAD, bool BUF>
-static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st) {
+template <int BN, bool DGRAD, bool BUF, int ATR = 0, int EPI = 0, bool MASK = true>
+static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st,
+                                   const GatherFuse* fuse = nullptr) {
   const int tiles_m = edrl_cdiv(g.M, 128), tiles_n = edrl_cdiv(g.NC, BN);
   const long nblk = (long)tiles_m * tiles_n;
   if (nblk <= 0) return 0;
@@ -312,13 +413,15 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   size_t lds = (size_t)2 * (128 + BN) * HLD * sizeof(__bf16);
   const size_t epi = (size_t)(4 * 32 * (BN / 2 + 4) + 4 * 3 * (BN / 2)) * sizeof(float);
   if (epi > lds) lds = epi;
-  auto kern = conv_gather_bf16_kernel<BN, DGRAD, BUF>;
+  auto kern = conv_gather_bf16_kernel<BN, DGRAD, BUF, ATR, EPI, MASK>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, g, tiles_n);
+  GatherFuse F;
+  if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, g, tiles_n, F);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
@@ -331,6 +434,24 @@ static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, 
                    (long)g.NC * g.Kfull * 2 < (1L << 31) && g.M < (1L << 31);
   if (buf) return launch_gather_bf16_impl<BN, DGRAD, true>(src, wm, dst, g, st);
   return launch_gather_bf16_impl<BN, DGRAD, false>(src, wm, dst, g, st);
+}
+
+static bool gather_fused_ok_bf16(const GatherGeom& g) {
+  const long ohw = (long)g.OHs * g.OWs;
+  return (g.SC % HBK == 0) && (g.NC % 4 == 0) && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 2 < (1L << 31) &&
+         (long)g.NC * g.Kfull * 2 < (1L << 31);
+}
+template <bool DGRAD, int ATR, int EPI>
+static int dispatch_gather_fused_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, const GatherFuse& F,
+                                      hipStream_t st) {
+  if (!gather_fused_ok_bf16(g)) return EDRL_EINVAL;
+  const bool mask = !(g.KH == 1 && g.KW == 1 && g.pad == 0);
+  if (g.NC <= 64) {
+    if (mask) return launch_gather_bf16_impl<64, DGRAD, true, ATR, EPI, true>(src, wm, dst, g, st, &F);
+    return launch_gather_bf16_impl<64, DGRAD, true, ATR, EPI, false>(src, wm, dst, g, st, &F);
+  }
+  if (mask) return launch_gather_bf16_impl<128, DGRAD, true, ATR, EPI, true>(src, wm, dst, g, st, &F);
+  return launch_gather_bf16_impl<128, DGRAD, true, ATR, EPI, false>(src, wm, dst, g, st, &F);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient (bf16)
@@ -364,9 +485,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int pitch, int pix
 
 // FASTLD: buffer-descriptor operand loads with a branch-free 32-bit pixel decode (same scheme as conv_gemm.hip's wgrad;
 // host-checked: WBK/OW + 1 <= OH, per-workgroup footprints < 2 GiB).
-template <int BM, int BN, bool FASTLD = false>
+// Fused BatchNorm operands (FASTLD only), as conv_gemm.hip's DYT / XT: DYT 2 forms dY = bf16(A*g + nK2*yraw + C2) from the
+// masked gradient (`dy`) and the raw conv output (F.dy2); XT 1 forms X = bf16(relu(x*scale + shift2)) from the raw previous conv
+// output; rows outside the split / padding taps are forced to 0 after the transform (MASKX: the layer has padding taps).
+struct WgradFuseH {
+  const __bf16* dy2;
+  const float* bcoef;    // [4][Co]: A, nK2, C2, mean
+  const float* xcoef;    // [5][SC]: mean, rstd, scale, shift, shift2
+};
+template <int BM, int BN, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
-                                                                 float* __restrict__ part, WgradGeomH g) {
+                                                                 float* __restrict__ part, WgradGeomH g, WgradFuseH F) {
+  static_assert((DYT == 0 && XT == 0) || FASTLD, "operand transforms ride on the buffer-descriptor path");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int PA = BM + 32, PB = BN + 32;          // LDS row pitch in elements (+64 bytes)
@@ -422,16 +552,38 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
   int b_ih[B_LD], b_iw[B_LD];
   int ih_lim = 0, iw_lim = 0, tapconst = 0, dw_step = 0, dh_step = 0;
   unsigned a_step = 0, c_step = 0, c_wrapw = 0, c_wraph = 0;
-  __amdgpu_buffer_rsrc_t rs_dy, rs_x;
+  __amdgpu_buffer_rsrc_t rs_dy, rs_x, rs_dy2;
+  unsigned dy_last = 0, x_last = 0;
+  f32x4 q[DYT == 2 ? 6 : 1];       // A, nK2, C2 of this thread's 8 output channels
+  f32x4 xq[XT == 1 ? 4 : 1];       // scale, shift2 of this thread's 8 input channels
+  bf16x8 a2_st[DYT == 2 ? A_LD : 1];
   if constexpr (FASTLD) {
     const long p_lo = t_begin * WBK;
     long p_hi = t_end * WBK; if (p_hi > g.P) p_hi = g.P;
     long rows = p_hi - p_lo; if (rows < 1) rows = 1;
     const unsigned ld2y = (unsigned)g.Co * 2u, ld2x = (unsigned)g.SC * 2u;
     rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p_lo * g.Co), 0, (int)(rows * ld2y), 0x00020000);
+    dy_last = (unsigned)(rows * ld2y) - 16u;
+    if constexpr (DYT == 2) {
+      rs_dy2 = __builtin_amdgcn_make_buffer_rsrc((void*)(F.dy2 + p_lo * g.Co), 0, (int)(rows * ld2y), 0x00020000);
+      const int co = co0 + ac8 * 8;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          q[2 * r + h] = co < g.Co ? *reinterpret_cast<const f32x4*>(F.bcoef + (long)r * g.Co + co + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (XT == 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        xq[h] = kvalid ? *reinterpret_cast<const f32x4*>(F.xcoef + 2 * (long)g.SC + kc + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        xq[2 + h] = kvalid ? *reinterpret_cast<const f32x4*>(F.xcoef + 4 * (long)g.SC + kc + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
     const long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + n_lo * g.SH * g.SW * g.SC), 0,
                                              (int)((n_hi - n_lo + 1) * g.SH * g.SW * ld2x), 0x00020000);
+    x_last = (unsigned)((n_hi - n_lo + 1) * g.SH * g.SW * ld2x) - 16u;
     const int co = co0 + ac8 * 8;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
@@ -457,6 +609,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         a_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_off[i], 0, 0));
+        if constexpr (DYT == 2) {
+          a2_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_dy2, (int)a_off[i], 0, 0));
+          a_ok[i] = a_off[i] <= dy_last;
+        }
         a_off[i] += a_step;
       }
 #pragma unroll
@@ -464,6 +620,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
         const bool ok = kvalid && (unsigned)b_ih[i] < (unsigned)g.SH && (unsigned)b_iw[i] < (unsigned)g.SW;
         const unsigned off = ok ? b_roff[i] + (unsigned)tapconst : OOBW;
         b_st[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+        if constexpr (XT == 1 && MASKX) b_ok[i] = off <= x_last;
         b_iw[i] += dw_step; b_ih[i] += dh_step; b_roff[i] += c_step;
         const bool w = b_iw[i] >= iw_lim;
         b_iw[i] -= w ? g.OW * g.stride : 0; b_ih[i] += w ? g.stride : 0; b_roff[i] += w ? c_wrapw : 0u;
@@ -490,6 +647,29 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
       while (bow[i] >= g.OW) { bow[i] -= g.OW; if (++boh[i] == g.OH) { boh[i] = 0; ++bn_[i]; } }
     }
   };
+  auto transform_tile = [&]() {
+    if constexpr (DYT == 2) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = (__bf16)__builtin_fmaf(q[2 + (e >> 2)][e & 3], (float)a2_st[i][e],
+                                        __builtin_fmaf(q[e >> 2][e & 3], (float)a_st[i][e], q[4 + (e >> 2)][e & 3]));
+        a_st[i] = a_ok[i] ? o : zero8;
+      }
+    }
+    if constexpr (XT == 1) {
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = (__bf16)fmaxf(__builtin_fmaf((float)b_st[i][e], xq[e >> 2][e & 3], xq[2 + (e >> 2)][e & 3]), 0.f);
+        if constexpr (MASKX) b_st[i] = b_ok[i] ? o : zero8; else b_st[i] = o;
+      }
+    }
+  };
   auto store_tile = [&](int buf) {
     __bf16* a = As + buf * WBK * PA;
     __bf16* b = Bs + buf * WBK * PB;
@@ -513,6 +693,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
   const int cgrp = 16 * ((lane >> 4) & 1);   // column block of this lane's 16-lane group inside the 32-wide MFMA tile
   if (t_begin < t_end) {
     load_tile();
+    transform_tile();
     store_tile(0);
     __syncthreads();
     for (long t = t_begin; t < t_end; ++t) {
@@ -535,7 +716,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const __bf16* _
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < t_end) store_tile(buf ^ 1);
+      if (t + 1 < t_end) { transform_tile(); store_tile(buf ^ 1); }
       __syncthreads();
     }
   }
@@ -703,10 +884,28 @@ size_t edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes(int N, int Ho, int Wo, int Co
   wgrad_plan_h((long)N * Ho * Wo, Co, KH * KW * Ci, &splits, &tps);
   return (size_t)splits * Co * KH * KW * Ci * sizeof(float);
 }
-// dw (fp32 [Co,KH,KW,Ci]) [+]= sum_pix dy (bf16) (x) x (bf16).  Co % 8 == 0 and Ci % 8 == 0.
-int edrl_conv2d_nhwc_wgrad_bf16(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_bytes, int N,
-                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
-                                int accumulate, hipStream_t st) {
+}  // extern "C"
+
+template <int DYT, int XT, bool MASKX>
+static void launch_wgrad_bf16(const __bf16* dy, const __bf16* x, float* ws, const WgradGeomH& g, long nblk, size_t lds,
+                              const WgradFuseH& F, hipStream_t st) {
+  auto kern = conv_wgrad_bf16_kernel<128, 128, true, DYT, XT, MASKX>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, x, ws, g, F);
+}
+
+static bool wgrad_fast_ok_h(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int tiles_per_split) {
+  const long span = (long)tiles_per_split * WBK;
+  return (WBK / Wo + 1 <= Ho) && span * Co * 2 < (1L << 31) && (span / ((long)Ho * Wo) + 2) * Hi * Wi * Ci * 2 < (1L << 31);
+}
+
+static int wgrad_bf16_impl(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_bytes, int N, int Hi,
+                           int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int accumulate,
+                           const WgradFuseH* fuse, hipStream_t st) {
   if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || (Co % 8) ||
       (Ci % 8))
     return EDRL_EINVAL;
@@ -722,29 +921,149 @@ int edrl_conv2d_nhwc_wgrad_bf16(const void* dy, const void* x, float* dw, float*
   constexpr int BM = 128, BN = 128;
   const size_t lds = (size_t)2 * WBK * ((BM + 32) + (BN + 32)) * sizeof(__bf16);
   static const bool fast_env = []() { const char* e = getenv("EDRL_WGRAD_FAST"); return !(e && e[0] == '0'); }();
-  const long span = (long)g.tiles_per_split * WBK;
-  const bool fast = fast_env && (WBK / Wo + 1 <= Ho) && span * Co * 2 < (1L << 31) &&
-                    (span / ((long)Ho * Wo) + 2) * Hi * Wi * Ci * 2 < (1L << 31);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  const bool fast_ok = wgrad_fast_ok_h(Hi, Wi, Ci, Ho, Wo, Co, g.tiles_per_split);
+  const bool fast = fast_env && fast_ok;
   g.tiles_x = edrl_cdiv(g.Ktot, BN); g.tiles_y = edrl_cdiv(Co, BM);
   const long nblk = (long)g.tiles_x * g.tiles_y * splits;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
-  if (fast)
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BM, BN, true>), dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy,
-                       (const __bf16*)x, workspace, g);
-  else
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BM, BN, false>), dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy,
-                       (const __bf16*)x, workspace, g);
+  if (fuse) {
+    if (!fast_ok || !fuse->dy2 || (((uintptr_t)fuse->dy2) & 15)) return EDRL_EINVAL;
+    const bool maskx = !(KH == 1 && KW == 1 && pad == 0);
+    if (fuse->xcoef && maskx) launch_wgrad_bf16<2, 1, true>((const __bf16*)dy, (const __bf16*)x, workspace, g, nblk, lds, *fuse, st);
+    else if (fuse->xcoef) launch_wgrad_bf16<2, 1, false>((const __bf16*)dy, (const __bf16*)x, workspace, g, nblk, lds, *fuse, st);
+    else launch_wgrad_bf16<2, 0, true>((const __bf16*)dy, (const __bf16*)x, workspace, g, nblk, lds, *fuse, st);
+  } else {
+    WgradFuseH F0;
+    memset(&F0, 0, sizeof(F0));
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    if (fast)
+      hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BM, BN, true>), dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy,
+                         (const __bf16*)x, workspace, g, F0);
+    else
+      hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BM, BN, false>), dim3((unsigned)nblk), dim3(256), lds, st, (const __bf16*)dy,
+                         (const __bf16*)x, workspace, g, F0);
+  }
   EDRL_LAUNCH_CHECK();
   const long n = (long)Co * g.Ktot;
   hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n, splits, accumulate);
   EDRL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" {
+// dw (fp32 [Co,KH,KW,Ci]) [+]= sum_pix dy (bf16) (x) x (bf16).  Co % 8 == 0 and Ci % 8 == 0.
+int edrl_conv2d_nhwc_wgrad_bf16(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_bytes, int N,
+                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                int accumulate, hipStream_t st) {
+  return wgrad_bf16_impl(dy, x, dw, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, accumulate,
+                         nullptr, st);
+}
+
+// ---- fused-BatchNorm variants of the bf16 trunk (same contracts as the _f32 entry points of conv_gemm.hip; bf16 tensors,
+// fp32 coefficient arrays fcoef [5][C] / bcoef [4][C])
+int edrl_conv2d_nhwc_wgrad_bn_bf16(const void* g_in, const void* yraw, const float* bcoef, const void* x, const float* x_fcoef,
+                                   float* dw, float* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int Ci, int Ho,
+                                   int Wo, int Co, int KH, int KW, int stride, int pad, int accumulate, hipStream_t st) {
+  if (!g_in || !yraw || !bcoef || !x) return EDRL_EINVAL;
+  WgradFuseH F;
+  F.dy2 = (const __bf16*)yraw; F.bcoef = bcoef; F.xcoef = x_fcoef;
+  return wgrad_bf16_impl(g_in, x, dw, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, accumulate, &F,
+                         st);
+}
+
+int edrl_conv2d_nhwc_fwd_bnin_stats_bf16(const void* x, const float* in_fcoef, const void* w, void* y, float* stat_part,
+                                         size_t stat_part_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                         int KW, int stride, int pad, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+      pad < 0 || (Ci % HBK) || (Co % 4) || !stat_part || !in_fcoef)
+    return EDRL_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 7)) return EDRL_EINVAL;
+  if ((long)N * Ho * Wo > 0x7fffffffL) return EDRL_EINVAL;
+  GatherGeom g;
+  g.M = (int)((long)N * Ho * Wo);
+  if (stat_part_bytes < (size_t)(((long)g.M + 127) / 128) * 3 * Co * sizeof(float)) return EDRL_ENOSPC;
+  g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_src = Ci; g.ld_dst = Co; g.ld_aux = 0; g.flags = GF_STATS;
+  g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
+  g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
+  g.stat_part = stat_part; g.stat_shift = nullptr;
+  GatherFuse F;
+  memset(&F, 0, sizeof(F));
+  F.acoef = in_fcoef;
+  return dispatch_gather_fused_bf16<false, 1, 0>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, F, st);
+}
+
+int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const float* bcoef, const void* wt, void* dx, int N,
+                                   int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                   int flags, const void* ep_raw, const unsigned char* ep_mask, const float* ep_fcoef,
+                                   int ep_relu, float* ep_part, size_t ep_part_bytes, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || !g_in || !yraw ||
+      !bcoef || (Co % HBK) || (Ci % 4))
+    return EDRL_EINVAL;
+  if (((uintptr_t)g_in & 15) || ((uintptr_t)yraw & 15) || ((uintptr_t)wt & 15) || ((uintptr_t)dx & 7)) return EDRL_EINVAL;
+  if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
+  if (ep_raw && (!ep_fcoef || !ep_part)) return EDRL_EINVAL;
+  long chunks = 0;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      const int h0 = ((ph - pad) % stride + stride) % stride, w0 = ((pw - pad) % stride + stride) % stride;
+      const long ohs = h0 < Hi ? (Hi - h0 + stride - 1) / stride : 0, ows = w0 < Wi ? (Wi - w0 + stride - 1) / stride : 0;
+      chunks += ((long)N * ohs * ows + 127) / 128;
+    }
+  if (ep_raw && ep_part_bytes < (size_t)chunks * 2 * Ci * sizeof(float)) return EDRL_ENOSPC;
+  int sshift = 0;
+  while ((1 << sshift) < stride) ++sshift;
+  if ((1 << sshift) != stride) return EDRL_EINVAL;
+  GatherGeom g;
+  g.OH = Hi; g.OW = Wi; g.NC = Ci; g.SH = Ho; g.SW = Wo; g.SC = Co;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Kfull = KH * KW * Co;
+  g.ld_src = Co; g.ld_dst = Ci; g.ld_aux = 0;
+  g.flags = (flags & GF_ACCUM) | ((ep_raw && !ep_mask && ep_relu) ? GF_EPI_RELU : 0);
+  g.step = stride; g.kstep = stride; g.sshift = sshift;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
+  GatherFuse F;
+  memset(&F, 0, sizeof(F));
+  F.src2 = yraw; F.acoef = bcoef;
+  if (ep_raw) { F.ep_x = ep_raw; F.ld_ep = Ci; F.ep_mask = ep_mask; F.ep_fcoef = ep_fcoef; F.ep_part = ep_part; }
+  int chunk0 = 0;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      g.h0 = ((ph - pad) % stride + stride) % stride;
+      g.w0 = ((pw - pad) % stride + stride) % stride;
+      g.OHs = g.h0 < Hi ? (Hi - g.h0 + stride - 1) / stride : 0;
+      g.OWs = g.w0 < Wi ? (Wi - g.w0 + stride - 1) / stride : 0;
+      if (g.OHs == 0 || g.OWs == 0) continue;
+      g.kh0 = ph; g.kw0 = pw;
+      g.KHs = ph < KH ? (KH - ph + stride - 1) / stride : 0;
+      g.KWs = pw < KW ? (KW - pw + stride - 1) / stride : 0;
+      g.Ktot = g.KHs * g.KWs * Co;
+      g.M = (int)((long)N * g.OHs * g.OWs);
+      if (g.Ktot == 0 && (flags & GF_ACCUM) && !ep_raw) continue;
+      F.ep_chunk0 = chunk0;
+      const int rc = ep_raw ? dispatch_gather_fused_bf16<true, 2, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)
+                            : dispatch_gather_fused_bf16<true, 2, 0>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st);
+      if (rc) return rc;
+      chunk0 += (g.M + 127) / 128;
+    }
+  return 0;
+}
+
+int edrl_conv2d_fused_ok_bf16(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || (Ci % HBK) || (Co % HBK) || (stride != 1 && stride != 2)) return 0;
+  if ((long)N * Hi * Wi > 0x7fffffffL || (long)N * Ho * Wo > 0x7fffffffL) return 0;
+  const long kfull = (long)KH * KW * Ci;
+  if (!((128 / ((long)Ho * Wo) + 2) * Hi * Wi * Ci * 2 < (1L << 31) && (long)Co * kfull * 2 < (1L << 31))) return 0;
+  const long cls = ((long)(Hi + stride - 1) / stride) * ((Wi + stride - 1) / stride);
+  if (!((128 / (cls > 0 ? cls : 1) + 3) * Ho * Wo * Co * 2 < (1L << 31))) return 0;
+  int splits, tps;
+  wgrad_plan_h((long)N * Ho * Wo, Co, (int)kfull, &splits, &tps);
+  return wgrad_fast_ok_h(Hi, Wi, Ci, Ho, Wo, Co, tps) ? 1 : 0;
 }
 
 int edrl_cast_f32_to_bf16(const float* in, void* out, long n, hipStream_t st) {

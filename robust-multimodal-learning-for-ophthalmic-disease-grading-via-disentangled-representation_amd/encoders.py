@@ -142,14 +142,14 @@ def _bcoef_from_partials(part, chunks, planes, M, gamma, fcoef):
     return bc, dgamma, dbeta
 
 
-def _bn_bwd_reduce(dout, mask, raw, fcoef, want_g):
+def _bn_bwd_reduce(K, dout, mask, raw, fcoef, want_g):
     """Standalone first half of a BatchNorm(+ReLU) backward: -> (g = dout*mask | dout itself, part, chunks, planes=3)."""
     C = raw.shape[-1]
     M = raw.numel() // C
     g = torch.empty_like(raw) if want_g else None
     ws, nbytes = _bn_ws(M, C, raw.device)
-    ops.call_timed_bytes("bn_bwd_reduce", M * C * (8.0 + (4.0 if want_g else 0.0) + (0.25 if mask is not None else 0.0)),
-                         "edrl_bn_bwd_reduce_f32", P(dout), P(mask), P(raw), P(fcoef), P(g), P(ws), nbytes, M, C)
+    ops.call_timed_bytes("bn_bwd_reduce", M * C * (2 * K.elt + (K.elt if want_g else 0.0) + (0.25 if mask is not None else 0.0)),
+                         K.reduce_name, P(dout), P(mask), P(raw), P(fcoef), P(g), P(ws), nbytes, M, C)
     return (g if want_g else dout), ws, (M + 1023) // 1024, 3
 
 
@@ -163,12 +163,127 @@ def _dbg_draw(g, raw, bc):
     return bc[0] * g + bc[1] * raw + bc[2]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Kernel sets: the trunk's forward/backward schedule (_TrunkFn) is written once; what differs between the fp32 trunk (C1/C3)
+# and the bf16 trunk (C2/C4: bf16 activations / gradients and bf16 MFMA convs, fp32 BatchNorm statistics, fp32 weights and
+# weight gradients, fp32 stem) is which launchers it calls.
+class _K32:
+    act_dtype = torch.float32
+    conv_bn_fwd = staticmethod(lambda *a, **k: _conv_bn_fwd(*a, **k))
+    bn_bwd = staticmethod(lambda *a, **k: _bn_bwd(*a, **k))
+    conv_wgrad = staticmethod(lambda dy, inp, wshape, s, p: ops.conv2d_wgrad(dy, inp, wshape, s, p))
+    conv_dgrad = staticmethod(lambda dy, wt, xshape, s, p, out=None, accumulate=False:
+                              ops.conv2d_dgrad(dy, wt, xshape, s, p, out=out, accumulate=accumulate))
+    permute = staticmethod(lambda w: ops.permute_weight(w))
+    fused_ok = staticmethod(lambda *a: ops.conv_fused_ok(*a))
+    fwd_stats = staticmethod(lambda inp, w, s, p: ops.conv2d_fwd_stats(inp, w, None, s, p))
+    fwd_bnin_stats = staticmethod(lambda raw, fc, w, s, p: ops.conv2d_fwd_bnin_stats(raw, fc, w, s, p))
+    wgrad_bn = staticmethod(lambda *a: ops.conv2d_wgrad_bn(*a))
+    dgrad_bn = staticmethod(lambda *a, **k: ops.conv2d_dgrad_bn(*a, **k))
+    apply_res_name, reduce_name, elt = "edrl_bn_apply_res_f32", "edrl_bn_bwd_reduce_f32", 4.0
+    grad_in = staticmethod(lambda dout: dout.contiguous())
+    feat_out = staticmethod(lambda cur: cur)
+
+    @staticmethod
+    def stem_fwd(T, x, p, bnd, cap, cb):
+        folded = False
+        if _STEM_S2D and not x.requires_grad:        # as a 4x4 conv over the space-to-depth image (ops.stem_conv_fwd)
+            raw, x_keep, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
+            a0, m0, r0, k0 = _bn_fwd(raw, bnd("bn1", p), True)
+            if cap is not None:
+                cap["conv1"] = dict(bn="bn1", inp=x, stride=2, pad=3, relu=True, residual=None, raw=raw, out=a0, mean=m0,
+                                    rstd=r0, mask=k0)
+        else:
+            raw, a0, m0, r0, k0 = cb("conv1", "bn1", x, 2, 3, True)
+            x_keep = x
+        N, H, W, C = a0.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        p0 = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        L.call("edrl_maxpool3x3s2_fwd_f32", P(a0), P(p0), P(idx), N, H, W, C)
+        if cap is not None:
+            cap["maxpool"] = dict(inp=a0, out=p0, idx=idx)
+        return p0, (x_keep, folded, raw, a0.shape, m0, r0, k0, idx)
+
+    @staticmethod
+    def stem_bwd(T, stem, p, dcur, grads, cap, bn_bwd, conv_bwd, needs_x):
+        x, folded, raw, a0_shape, m0, r0, k0, idx = stem
+        N, H, W, C = a0_shape
+        da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.float32)
+        L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
+        if cap is not None:
+            cap["maxpool"].update(dout=dcur, dinp=da0)
+        draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))
+        if folded:
+            grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), True)
+            if cap is not None:
+                cap["conv1"].update(d_raw=draw, dW=grads["conv1.weight"], dx_before=None, dx_after=None)
+            return None
+        return conv_bwd("conv1", draw, x, 2, 3, need_dx=needs_x)
+
+
+class _KBF16:
+    act_dtype = torch.bfloat16
+    conv_bn_fwd = staticmethod(lambda *a, **k: _conv_bn_fwd_bf16(*a, **k))
+    bn_bwd = staticmethod(lambda *a, **k: _bn_bwd_mx(*a, **k))
+    conv_wgrad = staticmethod(lambda dy, inp, wshape, s, p: ops.conv2d_wgrad_bf16(dy, inp, wshape, s, p))
+    conv_dgrad = staticmethod(lambda dy, wt, xshape, s, p, out=None, accumulate=False:
+                              ops.conv2d_dgrad_bf16(dy, wt, xshape, s, p, out=out, accumulate=accumulate))
+    permute = staticmethod(lambda w: ops.permute_weight_bf16(w))
+    fused_ok = staticmethod(lambda *a: ops.conv_fused_ok_bf16(*a))
+    fwd_stats = staticmethod(lambda inp, w, s, p: ops.conv2d_fwd_bf16(inp, ops.to_bf16(w), s, p, stats=True))
+    fwd_bnin_stats = staticmethod(lambda raw, fc, w, s, p: ops.conv2d_fwd_bnin_stats_bf16(raw, fc, ops.to_bf16(w), s, p))
+    wgrad_bn = staticmethod(lambda *a: ops.conv2d_wgrad_bn_bf16(*a))
+    dgrad_bn = staticmethod(lambda *a, **k: ops.conv2d_dgrad_bn_bf16(*a, **k))
+    apply_res_name, reduce_name, elt = "edrl_bn_apply_res_bf16", "edrl_bn_bwd_reduce_bf16", 2.0
+    grad_in = staticmethod(lambda dout: ops.to_bf16(dout.contiguous()))
+    feat_out = staticmethod(lambda cur: ops.to_f32(cur))
+
+    @staticmethod
+    def stem_fwd(T, x, p, bnd, cap, cb):
+        """fp32 stem conv + fp32 statistics, bf16 activation out."""
+        if _STEM_S2D:
+            raw, x, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
+        else:
+            raw, folded = ops.conv2d_fwd(x, p["conv1.weight"], stride=2, pad=3), False
+        bn = bnd("bn1", p)
+        C = raw.shape[-1]
+        M = raw.numel() // C
+        dev = raw.device
+        m0 = torch.empty(C, device=dev, dtype=torch.float32)
+        r0 = torch.empty_like(m0); scale = torch.empty_like(m0); shift = torch.empty_like(m0)
+        ws, nbytes = _bn_ws(M, C, dev)
+        L.call("edrl_bn_train_stats_f32", P(raw), M, C, C, P(bn["weight"]), P(bn["bias"]), P(bn["running_mean"]),
+               P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(m0), P(r0), P(scale), P(shift), P(ws), nbytes)
+        a0 = torch.empty(raw.shape, device=dev, dtype=torch.bfloat16)
+        k0 = torch.empty((M, C // 4), device=dev, dtype=torch.uint8)
+        L.call("edrl_bn_apply_mx", P(raw), 0, P(m0), P(scale), P(shift), None, P(a0), 1, P(k0), M, C, 1)
+        N, H, W, _ = a0.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        p0 = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.bfloat16)
+        idx = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.uint8)
+        L.call("edrl_maxpool3x3s2_fwd_bf16", P(a0), P(p0), P(idx), N, H, W, C)
+        return p0, (x, folded, raw, a0.shape, m0, r0, k0, idx)
+
+    @staticmethod
+    def stem_bwd(T, stem, p, dcur, grads, cap, bn_bwd, conv_bwd, needs_x):
+        x, folded, raw, a0_shape, m0, r0, k0, idx = stem
+        N, H, W, C = a0_shape
+        da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.bfloat16)
+        L.call("edrl_maxpool3x3s2_bwd_bf16", P(dcur), P(idx), P(da0), N, H, W, C)
+        draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))            # raw is fp32 -> fp32 gradient for the fp32 stem wgrad
+        grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), folded)
+        return None
+
+
 class _TrunkFn(torch.autograd.Function):
-    """x NHWC [N,H,W,Cin] -> feature map NHWC [N,h,w,C].  params: flat tensor list (see ResNetTrunk)."""
+    """x NHWC fp32 [N,H,W,Cin] -> feature map NHWC fp32 [N,h,w,C].  params: flat tensor list (see ResNetTrunk).  The kernel set
+    (T.kernels: _K32 | _KBF16) selects the storage type of activations / gradients and the launchers."""
 
     @staticmethod
     def forward(ctx, trunk, x, *params):
         T = trunk
+        K = T.kernels
         p = dict(zip(T.param_names, params))
         bnd = T.bn_dict
         saved = {}
@@ -177,7 +292,7 @@ class _TrunkFn(torch.autograd.Function):
         T._wt_cache = {}     # permuted weights are shared by the backward passes that follow this forward
 
         def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
-            r = _conv_bn_fwd(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
+            r = K.conv_bn_fwd(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
             if cap is not None:
                 cap[conv_name] = dict(bn=bn_name, inp=inp, stride=stride, pad=pad, relu=relu, residual=residual, raw=r[0],
                                       out=r[1], mean=r[2], rstd=r[3], mask=r[4])
@@ -187,9 +302,9 @@ class _TrunkFn(torch.autograd.Function):
             """fused unit: conv over `inp` (a raw tensor + its fcoef, or an activated tensor when in_fc is None)."""
             w = p[conv_name + ".weight"]
             if in_fc is None:
-                raw, part, chunks = ops.conv2d_fwd_stats(inp, w, None, stride, pad)
+                raw, part, chunks = K.fwd_stats(inp, w, stride, pad)
             else:
-                raw, part, chunks = ops.conv2d_fwd_bnin_stats(inp, in_fc, w, stride, pad)
+                raw, part, chunks = K.fwd_bnin_stats(inp, in_fc, w, stride, pad)
             C = raw.shape[-1]
             fc = _fcoef_from_partials(part, chunks, raw.numel() // C, C, bnd(bn_name, p))
             if cap is not None:
@@ -213,27 +328,9 @@ class _TrunkFn(torch.autograd.Function):
                 co = pl
             if blk["downsample"]:
                 geo.append((H, W, Ci, co, 1, s, 0))
-            return all(ops.conv_fused_ok(N, h, w, ci, c_o, k, st, pd) for h, w, ci, c_o, k, st, pd in geo)
+            return all(K.fused_ok(N, h, w, ci, c_o, k, st, pd) for h, w, ci, c_o, k, st, pd in geo)
 
-        # stem: as a 4x4 conv over the space-to-depth image when no input gradient is wanted (ops.stem_conv_fwd)
-        folded = False
-        if _STEM_S2D and not x.requires_grad:
-            raw, x_keep, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
-            a0, m0, r0, k0 = _bn_fwd(raw, bnd("bn1", p), True)
-            if cap is not None:
-                cap["conv1"] = dict(bn="bn1", inp=x, stride=2, pad=3, relu=True, residual=None, raw=raw, out=a0, mean=m0,
-                                    rstd=r0, mask=k0)
-        else:
-            raw, a0, m0, r0, k0 = cb("conv1", "bn1", x, 2, 3, True)
-            x_keep = x
-        N, H, W, C = a0.shape
-        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        p0 = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
-        idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
-        L.call("edrl_maxpool3x3s2_fwd_f32", P(a0), P(p0), P(idx), N, H, W, C)
-        saved["stem"] = (x_keep, folded, raw, a0.shape, m0, r0, k0, idx)
-        if cap is not None:
-            cap["maxpool"] = dict(inp=a0, out=p0, idx=idx)
+        p0, saved["stem"] = K.stem_fwd(T, x, p, bnd, cap, cb)
         cur = p0
         prev_fused = False
         for blk in T.blocks:
@@ -264,7 +361,7 @@ class _TrunkFn(torch.autograd.Function):
                 Ml = cl.numel() // Cl
                 out = torch.empty_like(cl)
                 kl = torch.empty((Ml, Cl // 4), device=cl.device, dtype=torch.uint8)
-                ops.call_timed_bytes("bn_apply_res", Ml * Cl * 12.25, "edrl_bn_apply_res_f32", P(cl), P(fl),
+                ops.call_timed_bytes("bn_apply_res", Ml * Cl * (3 * K.elt + 0.25), K.apply_res_name, P(cl), P(fl),
                                      P(cd if cd is not None else cur), P(fd), P(out), P(kl), Ml, Cl, 1)   # 2 reads + 1 write + sign bytes
                 rec.update(kl=kl)
                 if cap is not None:
@@ -298,11 +395,12 @@ class _TrunkFn(torch.autograd.Function):
         ctx.needs_x = x.requires_grad
         ctx.cap = cap
         T.bump_batches_tracked()
-        return cur
+        return K.feat_out(cur)
 
     @staticmethod
     def backward(ctx, dout):
         T, saved, p = ctx.trunk, ctx.saved, ctx.params
+        K = T.kernels
         ctx.saved = None
         grads = {}
         cap = ctx.cap
@@ -313,7 +411,7 @@ class _TrunkFn(torch.autograd.Function):
             key = (name, torch.cuda.current_stream().cuda_stream)     # (two-stream view overlap: one copy per stream)
             t = wt_cache.get(key)
             if t is None:
-                t = wt_cache[key] = ops.permute_weight(p[name + ".weight"])
+                t = wt_cache[key] = K.permute(p[name + ".weight"])
             return t
 
         # Weight gradients are off the critical chain (dgrad -> BN backward -> dgrad ...): they are issued on a side
@@ -324,13 +422,13 @@ class _TrunkFn(torch.autograd.Function):
         def conv_bwd(name, dy, inp, stride, pad, need_dx=True, dx_out=None, accumulate=False):
             w = p[name + ".weight"]
             if side is None:
-                grads[name + ".weight"] = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+                grads[name + ".weight"] = K.conv_wgrad(dy, inp, tuple(w.shape), stride, pad)
                 if cap is not None:
                     cap[name].update(d_raw=dy, dW=grads[name + ".weight"],
                                      dx_before=dx_out.clone() if (accumulate and dx_out is not None) else None)
                 if not need_dx:
                     return None
-                dx = ops.conv2d_dgrad(dy, wt_of(name), tuple(inp.shape), stride, pad, out=dx_out, accumulate=accumulate)
+                dx = K.conv_dgrad(dy, wt_of(name), tuple(inp.shape), stride, pad, out=dx_out, accumulate=accumulate)
                 if cap is not None:
                     cap[name]["dx_after"] = dx.clone()
                 return dx
@@ -340,16 +438,16 @@ class _TrunkFn(torch.autograd.Function):
             main.wait_stream(side)
             dx = None
             if need_dx:
-                dx = ops.conv2d_dgrad(dy, wt_of(name), tuple(inp.shape), stride, pad, out=dx_out, accumulate=accumulate)
+                dx = K.conv_dgrad(dy, wt_of(name), tuple(inp.shape), stride, pad, out=dx_out, accumulate=accumulate)
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):
-                dw = ops.conv2d_wgrad(dy, inp, tuple(w.shape), stride, pad)
+                dw = K.conv_wgrad(dy, inp, tuple(w.shape), stride, pad)
             dy.record_stream(side); inp.record_stream(side); dw.record_stream(main)
             grads[name + ".weight"] = dw
             return dx
 
         def bn_bwd(name, dy, mask, raw, st, want_dres=False):
-            d_raw, dg, db, dres = _bn_bwd(dy, mask, raw, st[0], st[1], p[name + ".weight"], want_dres)
+            d_raw, dg, db, dres = K.bn_bwd(dy, mask, raw, st[0], st[1], p[name + ".weight"], want_dres)
             grads[name + ".weight"] = dg
             grads[name + ".bias"] = db
             if cap is not None:
@@ -367,7 +465,7 @@ class _TrunkFn(torch.autograd.Function):
 
         def fwgrad(name, g, raw, bc, xin, x_fc, stride, pad):
             w = p[name + ".weight"]
-            grads[name + ".weight"] = ops.conv2d_wgrad_bn(g, raw, bc, xin, x_fc, tuple(w.shape), stride, pad)
+            grads[name + ".weight"] = K.wgrad_bn(g, raw, bc, xin, x_fc, tuple(w.shape), stride, pad)
 
         def fcap(conv_name, bn_name, g, raw, bc, dres=None):
             if cap is not None:
@@ -378,7 +476,7 @@ class _TrunkFn(torch.autograd.Function):
 
         def fdgrad(name, g, raw, bc, x_shape, stride, pad, out=None, accumulate=False, ep=None, ep_keep=None):
             before = out.clone() if (cap is not None and accumulate) else None
-            r = ops.conv2d_dgrad_bn(g, raw, bc, wt_of(name), tuple(x_shape), stride, pad, out=out, accumulate=accumulate, ep=ep)
+            r = K.dgrad_bn(g, raw, bc, wt_of(name), tuple(x_shape), stride, pad, out=out, accumulate=accumulate, ep=ep)
             if cap is not None:
                 cap[name].update(dx_before=before, dx_after=(r if ep is None else r[0]).clone(),
                                  dx_keep=ep_keep() if (ep is not None and ep_keep is not None) else None)
@@ -413,7 +511,7 @@ class _TrunkFn(torch.autograd.Function):
                 res, rfc = (rj["cd"], rj["fd"]) if T.blocks[j]["downsample"] else (get_x(j), None)
                 t = torch.empty_like(cl)
                 Cl = cl.shape[-1]
-                ops.call_timed_bytes("bn_apply_res", cl.numel() * 12.0, "edrl_bn_apply_res_f32", P(cl), P(fl), P(res), P(rfc),
+                ops.call_timed_bytes("bn_apply_res", cl.numel() * 3 * K.elt, K.apply_res_name, P(cl), P(fl), P(res), P(rfc),
                                      P(t), None, cl.numel() // Cl, Cl, 1)
                 out_cache[j] = t
             return t
@@ -422,7 +520,7 @@ class _TrunkFn(torch.autograd.Function):
             xj = saved[T.blocks[j]["name"]]["x"]
             return xj if xj is not None else get_out(j - 1)
 
-        grad_in = ("plain", dout.contiguous())
+        grad_in = ("plain", K.grad_in(dout))
         for bi in range(len(T.blocks) - 1, -1, -1):
             blk = T.blocks[bi]
             pre, s = blk["name"], blk["stride"]
@@ -435,7 +533,7 @@ class _TrunkFn(torch.autograd.Function):
                 last, last_bn = (pre + ".conv3", pre + ".bn3") if bott else (pre + ".conv2", pre + ".bn2")
                 cl, fl = (rec["c3"], rec["f3"]) if bott else (rec["c2"], rec["f2"])
                 if grad_in[0] == "plain":
-                    gl, part, chunks, planes = _bn_bwd_reduce(grad_in[1], rec["kl"], cl, fl, want_g=True)
+                    gl, part, chunks, planes = _bn_bwd_reduce(K, grad_in[1], rec["kl"], cl, fl, want_g=True)
                 else:
                     _, gl, part, chunks, planes = grad_in
                 bl = fin_bwd(last_bn, part, chunks, planes, cl, fl)
@@ -465,7 +563,7 @@ class _TrunkFn(torch.autograd.Function):
                 # its epilogue sees the complete gradient of the block below's output
                 if blk["downsample"]:
                     cd, fd = rec["cd"], rec["fd"]
-                    _, partd, chunksd, planesd = _bn_bwd_reduce(gl, None, cd, fd, want_g=False)
+                    _, partd, chunksd, planesd = _bn_bwd_reduce(K, gl, None, cd, fd, want_g=False)
                     bd = fin_bwd(pre + ".downsample.1", partd, chunksd, planesd, cd, fd)
                     fwgrad(pre + ".downsample.0", gl, cd, bd, xin, None, s, 0)
                     fcap(pre + ".downsample.0", pre + ".downsample.1", gl, cd, bd)
@@ -509,26 +607,12 @@ class _TrunkFn(torch.autograd.Function):
             del g
             if ep_lo is not None:            # the block below is fused: hand it the masked gradient + partial sums
                 lo_raw, lo_mask, lo_fc, _ = ep_lo
-                gl, part, chunks, planes = _bn_bwd_reduce(dx, lo_mask, lo_raw, lo_fc, want_g=True)
+                gl, part, chunks, planes = _bn_bwd_reduce(K, dx, lo_mask, lo_raw, lo_fc, want_g=True)
                 grad_in = ("masked", gl, part, chunks, planes)
             else:
                 grad_in = ("plain", dx)
             del rec, saved[pre]
-        dcur = grad_in[1]
-        x, folded, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
-        N, H, W, C = a0_shape
-        da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.float32)
-        L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
-        if cap is not None:
-            cap["maxpool"].update(dout=dcur, dinp=da0)
-        draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))
-        if folded:
-            grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), True)
-            if cap is not None:
-                cap["conv1"].update(d_raw=draw, dW=grads["conv1.weight"], dx_before=None, dx_after=None)
-            dx = None
-        else:
-            dx = conv_bwd("conv1", draw, x, 2, 3, need_dx=ctx.needs_x)
+        dx = K.stem_bwd(T, saved.pop("stem"), p, grad_in[1], grads, cap, bn_bwd, conv_bwd, ctx.needs_x)
         if side is not None:
             main.wait_stream(side)
         return (None, dx) + tuple(grads.get(n) for n in T.param_names)
@@ -579,125 +663,6 @@ def _bn_bwd_mx(dout, mask, raw, mean, rstd, gamma, want_dres):
     return d_raw, dgamma, dbeta, dres
 
 
-class _TrunkBf16Fn(torch.autograd.Function):
-    """The same trunk with bf16 activations / gradients and bf16 MFMA convolutions (fp32 accumulate; BatchNorm statistics,
-    affine and all reductions in fp32; weights and their gradients fp32).  The stem conv (Cin = 1 or 4) stays fp32.
-    x NHWC fp32 -> feature map NHWC fp32 (cast once at the boundary to the fp32 head)."""
-
-    @staticmethod
-    def forward(ctx, trunk, x, *params):
-        T = trunk
-        p = dict(zip(T.param_names, params))
-        bnd = T.bn_dict
-        saved = {}
-        x = ops._chk(x, "encoder input")
-
-        def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
-            return _conv_bn_fwd_bf16(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
-
-        # stem: fp32 conv + fp32 statistics, bf16 activation out
-        if _STEM_S2D:
-            raw, x, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
-        else:
-            raw, folded = ops.conv2d_fwd(x, p["conv1.weight"], stride=2, pad=3), False
-        bn = bnd("bn1", p)
-        C = raw.shape[-1]
-        M = raw.numel() // C
-        dev = raw.device
-        m0 = torch.empty(C, device=dev, dtype=torch.float32)
-        r0 = torch.empty_like(m0); scale = torch.empty_like(m0); shift = torch.empty_like(m0)
-        ws, nbytes = _bn_ws(M, C, dev)
-        L.call("edrl_bn_train_stats_f32", P(raw), M, C, C, P(bn["weight"]), P(bn["bias"]), P(bn["running_mean"]),
-               P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(m0), P(r0), P(scale), P(shift), P(ws), nbytes)
-        a0 = torch.empty(raw.shape, device=dev, dtype=torch.bfloat16)
-        k0 = torch.empty((M, C // 4), device=dev, dtype=torch.uint8)
-        L.call("edrl_bn_apply_mx", P(raw), 0, P(m0), P(scale), P(shift), None, P(a0), 1, P(k0), M, C, 1)
-        N, H, W, _ = a0.shape
-        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        p0 = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.bfloat16)
-        idx = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.uint8)
-        L.call("edrl_maxpool3x3s2_fwd_bf16", P(a0), P(p0), P(idx), N, H, W, C)
-        saved["stem"] = (x, folded, raw, a0.shape, m0, r0, k0, idx)
-        cur = p0
-        for blk in T.blocks:
-            pre, s = blk["name"], blk["stride"]
-            rec = {"x": cur}
-            if blk["downsample"]:
-                cd, idn, md, rd, _ = cb(pre + ".downsample.0", pre + ".downsample.1", cur, s, 0, False)
-                rec.update(cd=cd, sd=(md, rd))
-            else:
-                idn = cur
-            if T.kind == "bottleneck":
-                c1, a1, m1, r1, k1 = cb(pre + ".conv1", pre + ".bn1", cur, 1, 0, True)
-                c2, a2, m2, r2, k2 = cb(pre + ".conv2", pre + ".bn2", a1, s, 1, True)
-                c3, out, ml, rl, kl = cb(pre + ".conv3", pre + ".bn3", a2, 1, 0, True, residual=idn)
-                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2, a2=a2, s2=(m2, r2), k2=k2, c3=c3)
-            else:
-                c1, a1, m1, r1, k1 = cb(pre + ".conv1", pre + ".bn1", cur, s, 1, True)
-                c2, out, ml, rl, kl = cb(pre + ".conv2", pre + ".bn2", a1, 1, 1, True, residual=idn)
-                rec.update(c1=c1, a1=a1, s1=(m1, r1), k1=k1, c2=c2)
-            rec.update(sl=(ml, rl), kl=kl)
-            saved[pre] = rec
-            cur = out
-        ctx.trunk, ctx.saved, ctx.params = T, saved, p
-        T.bump_batches_tracked()
-        return ops.to_f32(cur)
-
-    @staticmethod
-    def backward(ctx, dout):
-        T, saved, p = ctx.trunk, ctx.saved, ctx.params
-        ctx.saved = None
-        grads = {}
-        dcur = ops.to_bf16(dout.contiguous())
-
-        def conv_bwd(name, dy, inp, stride, pad, dx_out=None, accumulate=False):
-            w = p[name + ".weight"]
-            grads[name + ".weight"] = ops.conv2d_wgrad_bf16(dy, inp, tuple(w.shape), stride, pad)
-            return ops.conv2d_dgrad_bf16(dy, ops.permute_weight_bf16(w), tuple(inp.shape), stride, pad, out=dx_out,
-                                         accumulate=accumulate)
-
-        def bn_bwd(name, dy, mask, raw, st, want_dres=False):
-            d_raw, dg, db, dres = _bn_bwd_mx(dy, mask, raw, st[0], st[1], p[name + ".weight"], want_dres)
-            grads[name + ".weight"] = dg
-            grads[name + ".bias"] = db
-            return d_raw, dres
-
-        for blk in reversed(T.blocks):
-            pre, s = blk["name"], blk["stride"]
-            rec = saved.pop(pre)
-            xin = rec["x"]
-            last = "c3" if T.kind == "bottleneck" else "c2"
-            last_bn = pre + (".bn3" if T.kind == "bottleneck" else ".bn2")
-            d3, g = bn_bwd(last_bn, dcur, rec["kl"], rec[last], rec["sl"], want_dres=True)
-            if T.kind == "bottleneck":
-                da2 = conv_bwd(pre + ".conv3", d3, rec["a2"], 1, 0)
-                d2, _ = bn_bwd(pre + ".bn2", da2, rec["k2"], rec["c2"], rec["s2"])
-                da1 = conv_bwd(pre + ".conv2", d2, rec["a1"], s, 1)
-                d1, _ = bn_bwd(pre + ".bn1", da1, rec["k1"], rec["c1"], rec["s1"])
-                c1_stride, c1_pad = 1, 0
-            else:
-                da1 = conv_bwd(pre + ".conv2", d3, rec["a1"], 1, 1)
-                d1, _ = bn_bwd(pre + ".bn1", da1, rec["k1"], rec["c1"], rec["s1"])
-                c1_stride, c1_pad = s, 1
-            if blk["downsample"]:
-                dx = conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad)
-                dd, _ = bn_bwd(pre + ".downsample.1", g, None, rec["cd"], rec["sd"])
-                conv_bwd(pre + ".downsample.0", dd, xin, s, 0, dx_out=dx, accumulate=True)
-            else:
-                dx = g
-                conv_bwd(pre + ".conv1", d1, xin, c1_stride, c1_pad, dx_out=dx, accumulate=True)
-            dcur = dx
-            del rec, g
-        x, folded, raw, a0_shape, m0, r0, k0, idx = saved.pop("stem")
-        N, H, W, C = a0_shape
-        da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.bfloat16)
-        L.call("edrl_maxpool3x3s2_bwd_bf16", P(dcur), P(idx), P(da0), N, H, W, C)
-        draw, _ = bn_bwd("bn1", da0, k0, raw, (m0, r0))            # raw is fp32 -> fp32 gradient for the fp32 stem wgrad
-        w1 = p["conv1.weight"]
-        grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(w1.shape), folded)
-        return (None, None) + tuple(grads.get(n) for n in T.param_names)
-
-
 class ResNetTrunk(nn.Module):
     """ResNet-18/34/50 trunk (no fc), NHWC fp32, HIP kernels only."""
 
@@ -734,6 +699,7 @@ class ResNetTrunk(nn.Module):
         self.param_names = [n for n, _ in self.named_parameters()]
         self._capture = None
         self._wt_cache = {}
+        self.kernels = _KBF16 if dtype == "bf16" else _K32
         self._register_state_dict_hook(self._save_hook)
         self._register_load_state_dict_pre_hook(self._load_pre_hook)
         # True: do not keep the residual blocks' outputs for backward (rebuilt there from the raw conv outputs: one extra
@@ -850,8 +816,6 @@ class ResNetTrunk(nn.Module):
         if not self.training:
             return self.forward_eval(x_nhwc)
         params = [self.get(n) for n in self.param_names]
-        if self.compute_dtype == "bf16":
-            return _TrunkBf16Fn.apply(self, x_nhwc, *params)
         return _TrunkFn.apply(self, x_nhwc, *params)
 
     @torch.no_grad()

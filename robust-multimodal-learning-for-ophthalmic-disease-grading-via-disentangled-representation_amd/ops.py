@@ -1049,3 +1049,59 @@ def conv2d_wgrad_bf16(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=Fals
     _launch_timed("conv_wgrad_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_bf16", P(dy), P(x),
                   P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 1 if accumulate else 0)
     return out
+
+
+# ---- fused-BatchNorm variants of the bf16 trunk (bf16 tensors, fp32 coefficient arrays; see conv2d_*_bn above)
+def conv_fused_ok_bf16(N, Hi, Wi, Ci, Co, KH, stride, pad):
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KH) // stride + 1
+    return bool(L.query("edrl_conv2d_fused_ok_bf16", N, Hi, Wi, Ci, Ho, Wo, Co, KH, KH, stride, pad))
+
+
+def conv2d_fwd_bnin_stats_bf16(x_raw, in_fcoef, w, stride=1, pad=0):
+    N, Hi, Wi, Ci = x_raw.shape
+    Co, KH, KW, _ = w.shape
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    out = torch.empty((N, Ho, Wo, Co), device=x_raw.device, dtype=torch.bfloat16)
+    chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
+    part = torch.empty((chunks, 3, Co), device=x_raw.device, dtype=torch.float32)
+    _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_bnin_stats_bf16", P(x_raw),
+                  P(in_fcoef), P(w), P(out), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad,
+                  nbytes=2.0 * (x_raw.numel() + w.numel() + out.numel()))
+    return out, part, chunks
+
+
+def conv2d_dgrad_bn_bf16(g, yraw, bcoef, wt, x_shape, stride=1, pad=0, out=None, accumulate=False, ep=None):
+    N, Hi, Wi, Ci = x_shape
+    _, Ho, Wo, Co = g.shape
+    KH, KW = wt.shape[1], wt.shape[2]
+    if out is None:
+        out = torch.empty((N, Hi, Wi, Ci), device=g.device, dtype=torch.bfloat16)
+        accumulate = False
+    part, chunks, nbytes = None, 0, 0
+    if ep is not None:
+        chunks = L.query("edrl_conv_dgrad_bn_chunks", N, Hi, Wi, stride, pad)
+        part = torch.empty((chunks, 2, Ci), device=g.device, dtype=torch.float32)
+        nbytes = part.numel() * 4
+    ep_raw, ep_mask, ep_fcoef, ep_relu = ep if ep is not None else (None, None, None, False)
+    kernels = _dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate and ep is None)
+    _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bn_bf16", P(g), P(yraw),
+                  P(bcoef), P(wt), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0,
+                  P(ep_raw), P(ep_mask), P(ep_fcoef), 1 if ep_relu else 0, P(part), nbytes, kernels=kernels,
+                  nbytes=2.0 * (2 * g.numel() + wt.numel() + out.numel() * (2 if accumulate else 1) +
+                                (out.numel() if ep is not None else 0)))
+    return out if ep is None else (out, part, chunks)
+
+
+def conv2d_wgrad_bn_bf16(g, yraw, bcoef, x, x_fcoef, w_shape, stride=1, pad=0):
+    N, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = g.shape
+    KH, KW = w_shape[1], w_shape[2]
+    out = torch.empty(w_shape, device=g.device, dtype=torch.float32)
+    nbytes = L.query("edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
+    ws = torch.empty(nbytes // 4, device=g.device, dtype=torch.float32)
+    _launch_timed("conv_wgrad_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_bn_bf16", P(g), P(yraw),
+                  P(bcoef), P(x), P(x_fcoef), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 0,
+                  nbytes=2.0 * (2 * g.numel() + x.numel()) + 4.0 * out.numel())
+    return out

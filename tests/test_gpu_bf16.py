@@ -93,15 +93,20 @@ def test_conv_bf16_fused_stats_and_casts(edrl, dev):
     check("bf16 fused rstd", outs[1].cpu(), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-4)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("depth,in_ch,N,H,dropped", [(18, 1, 8, 96, False), (50, 3, 4, 128, False),
                                                      (18, 1, 8, 96, True), (50, 1, 4, 128, True)])
-def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, dropped, monkeypatch):
+def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, dropped, fused, monkeypatch):
     """bf16 trunk (bf16 MFMA convs, bf16 activations/gradients, fp32 BN statistics) against the fp64 oracle.
 
     dropped=True is config C4's missing-modality view (BASELINE.json configs[4]; data_harvard.py:333-334: the OCT volume of
     the second view is all zeros): the stem conv output is identically 0, so the first BatchNorm sees EXACTLY zero variance
     (rstd = eps^-1/2, output = relu(beta)) and every later one sees only the variance the zero padding of a constant image
     creates -- through edrl_bn_apply_mx / edrl_bn_bwd_mx.  Random non-zero beta/gamma keep the pass non-trivial.
+
+    fused=False runs the separate BatchNorm passes (EDRL_FUSE_BN=0) so that the per-layer hook (1) sees every conv+BN call;
+    fused=True runs the default fused-BatchNorm blocks (BN+ReLU in the consumer conv's operand load, BatchNorm backward from the
+    data-gradient epilogue, d_raw formed in the dgrad / wgrad loads) and is held to the same end-to-end criteria (2) and (3).
 
     (1) PER LAYER, tight: every conv->BN->(+res)->(ReLU) call the trunk makes is re-done by the oracle's storage-aware
         fp64 op (oracle/resnet_oracle.conv_bn_bf16_op) on the product's own bf16 inputs.  What is left is accumulation
@@ -139,6 +144,7 @@ def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, droppe
     f_full.backward(gy.double())
     f_q.backward(gy.double())
 
+    monkeypatch.setattr(E, "_FUSE_BN", fused)
     product_op = E._conv_bn_fwd_bf16
     worst = dict(raw=0.0, out=0.0, mean=0.0, rstd=0.0, n=0)
 
@@ -166,11 +172,15 @@ def test_trunk_bf16_per_layer_and_envelope(edrl, dev, depth, in_ch, N, H, droppe
     n_convs = sum(1 for n in trunk.param_names if n.endswith(".weight") and "conv" in n or "downsample.0" in n) - 1
     print(f"[parity] bf16 trunk{depth}: {worst['n']} conv+BN layers checked per layer: raw {worst['raw']:.2e} "
           f"out {worst['out']:.2e} (tol 3e-4)  mean {worst['mean']:.2e} rstd {worst['rstd']:.2e} (tol 1e-5)")
-    assert worst["n"] == n_convs
+    if fused:
+        assert worst["n"] < n_convs, "the fused blocks must not go through the separate conv+BN path"
+    else:
+        assert worst["n"] == n_convs
     # dropped view: a layer's input is (nearly) one value per channel, so a 1-ulp(bf16) rounding flip of that value moves
     # thousands of equal elements together -- the norm-wise bound is looser there (1e-3; one bf16 ulp is 3.9e-3)
     tol = 1e-3 if dropped else 3e-4
-    assert worst["raw"] < tol and worst["out"] < tol and worst["mean"] < 1e-5 and worst["rstd"] < 1e-5
+    if worst["n"]:
+        assert worst["raw"] < tol and worst["out"] < tol and worst["mean"] < 1e-5 and worst["rstd"] < 1e-5
 
     fh = f.permute(0, 3, 1, 2).cpu().double()
     rel = lambda a, b: float((a - b).norm() / b.norm())
@@ -261,3 +271,62 @@ def test_bn_mx_kernels_vs_torch(edrl, dev):
     god = go.to(dev)
     L.call("edrl_maxpool3x3s2_bwd_bf16", P(god), P(idx), P(dxd), N_, H_, W_, C_)
     check("maxpool_bwd_bf16", dxd.float().cpu().permute(0, 3, 1, 2), xr.grad, 2 ** -8)
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", [(4, 14, 14, 64, 128, 3, 1, 1), (3, 12, 10, 128, 64, 1, 1, 0), (2, 16, 16, 64, 128, 3, 2, 1),
+                                               (2, 8, 8, 256, 512, 1, 2, 0)])
+def test_bf16_fused_bn_conv_kernels_vs_fp64(edrl, dev, N, H, W, Ci, Co, k, s, p):
+    """The fused-BatchNorm bf16 launchers against fp64 on the same bf16 operands with the product's storage roundings: forward with
+    BN+ReLU in the operand load (+ BatchNorm partials of the output), data gradient with d_raw formed in the operand load and the
+    masked result + (sum g, sum g*x) from the epilogue, weight gradient with both operand transforms.  bf16 outputs: 2^-7 of the
+    tensor max element-wise (one rounding of the operand + one of the result); fp32 sums / weight gradients 2e-3."""
+    ops, L = edrl.ops, edrl._lib
+    P = L.ptr
+    if not ops.conv_fused_ok_bf16(N, H, W, Ci, Co, k, s, p):
+        pytest.skip("geometry without the fused bf16 fast paths")
+    g = torch.Generator().manual_seed(N * 100 + Co)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    q = lambda t: t.bfloat16()
+    x = q(torch.randn(N, H, W, Ci, generator=g))                 # raw conv output of the layer below (bf16 storage)
+    w = torch.randn(Co, k, k, Ci, generator=g) * 0.1
+    fin = torch.empty(5, Ci); fin[0].normal_(generator=g); fin[1].fill_(1.0); fin[2] = 0.5 + torch.rand(Ci, generator=g)
+    fin[3].normal_(generator=g); fin[4] = fin[3] - fin[0] * fin[2]
+    nchw = lambda t: t.double().permute(0, 3, 1, 2)
+    act = q(torch.relu(x.float() * fin[2] + fin[4]))             # what the consumer forms on the fly, rounded to bf16 storage
+    wq = q(w)
+    y64 = F.conv2d(nchw(act), wq.double().permute(0, 3, 1, 2), stride=s, padding=p)
+    xd, find = x.to(dev), fin.to(dev)
+    y, part, chunks = ops.conv2d_fwd_bnin_stats_bf16(xd, find, wq.to(dev), s, p)
+    check("bf16 fused fwd", nchw(y.float().cpu()), y64, 2 ** -7)
+    # BatchNorm partials of the (unrounded) output -> mean / rstd
+    fc = torch.empty(5, Co, device=dev)
+    gb = L.query("edrl_bn_finalize_group_ws_bytes", chunks, Co)
+    gws = torch.empty(max(gb // 8, 1), device=dev, dtype=torch.float64)
+    L.call("edrl_bn_finalize_fcoef_f32", P(part), chunks, 128, N * Ho * Wo, Co, None, None, None, None, 0.1, 1e-5, P(fc), P(gws), gb)
+    check("bf16 fused fwd mean", fc[0].cpu(), y64.mean(dim=(0, 2, 3)), 1e-3)
+    check("bf16 fused fwd rstd", fc[1].cpu(), torch.rsqrt(y64.var(dim=(0, 2, 3), unbiased=False) + 1e-5), 1e-3)
+    # ---- backward operands
+    gy = q(torch.randn(N, Ho, Wo, Co, generator=g))              # masked upstream gradient g of this layer's BatchNorm output
+    yraw = q(torch.randn(N, Ho, Wo, Co, generator=g))            # this layer's raw conv output
+    bc = torch.empty(4, Co); bc[0] = 0.5 + torch.rand(Co, generator=g); bc[1] = 0.02 * torch.randn(Co, generator=g)
+    bc[2] = 0.02 * torch.randn(Co, generator=g); bc[3].zero_()
+    draw = q(bc[0] * gy.float() + bc[1] * yraw.float() + bc[2])  # d_raw as the consumers form it, bf16 storage
+    a64 = nchw(act).requires_grad_(True)
+    w64 = wq.double().permute(0, 3, 1, 2).requires_grad_(True)
+    F.conv2d(a64, w64, stride=s, padding=p).backward(nchw(draw))
+    gyd, yrawd, bcd = gy.to(dev), yraw.to(dev), bc.to(dev)
+    wt = ops.permute_weight_bf16(w.to(dev))
+    dx, part2, ch2 = ops.conv2d_dgrad_bn_bf16(gyd, yrawd, bcd, wt, (N, H, W, Ci), s, p, ep=(xd, None, find, True))
+    pre = nchw(x.float() * fin[2] + fin[4])
+    keep = (pre > 0).double()
+    care = (pre.abs() > 1e-6 * pre.abs().max()).double()
+    ref_dx = a64.grad * keep
+    err = ((nchw(dx.float().cpu()) - ref_dx) * care).abs().max() / ref_dx.abs().max()
+    print(f"[parity] bf16 fused dgrad+epilogue: max-rel-err {err:.3e} (tol {2 ** -7:.1e})")
+    assert err <= 2 ** -7
+    s_g = (ref_dx * care).sum(dim=(0, 2, 3)); s_gx = (ref_dx * care * nchw(x)).sum(dim=(0, 2, 3))
+    got = part2.double().sum(0).cpu()
+    scale_g = ref_dx.abs().sum(dim=(0, 2, 3)).max()
+    assert ((got[0] - s_g).abs().max() / scale_g) < 2e-3 and ((got[1] - s_gx).abs().max() / (ref_dx.abs() * nchw(x).abs()).sum(dim=(0, 2, 3)).max()) < 2e-3
+    dw = ops.conv2d_wgrad_bn_bf16(gyd, yrawd, bcd, xd, find, (Co, k, k, Ci), s, p)
+    check("bf16 fused wgrad", dw.cpu().permute(0, 3, 1, 2), w64.grad, 2e-3)
