@@ -181,6 +181,7 @@ class _K32:
     wgrad_bn = staticmethod(lambda *a: ops.conv2d_wgrad_bn(*a))
     dgrad_bn = staticmethod(lambda *a, **k: ops.conv2d_dgrad_bn(*a, **k))
     apply_res_name, reduce_name, elt = "edrl_bn_apply_res_f32", "edrl_bn_bwd_reduce_f32", 4.0
+    fuse_max_planes = 1 << 30        # every residual stage takes the fused-BatchNorm path
     grad_in = staticmethod(lambda dout: dout.contiguous())
     feat_out = staticmethod(lambda cur: cur)
 
@@ -236,6 +237,10 @@ class _KBF16:
     wgrad_bn = staticmethod(lambda *a: ops.conv2d_wgrad_bn_bf16(*a))
     dgrad_bn = staticmethod(lambda *a, **k: ops.conv2d_dgrad_bn_bf16(*a, **k))
     apply_res_name, reduce_name, elt = "edrl_bn_apply_res_bf16", "edrl_bn_bwd_reduce_bf16", 2.0
+    # Next to the bf16 MFMA (16x the fp32 rate) the operand transforms are 57-60 VALU per 8-MFMA K tile: the fused kernels turn
+    # VALU-bound on the compute-heavy stages (profiles/r02_fused_layers_bf16_2112img.txt: stage-3/4 blocks lose 0.3-0.8 ms per
+    # 2112 images, stage-1/2 blocks -- HBM-bound, wide BatchNorm tensors -- gain 0.7-2.5 ms), so only blocks up to this width fuse.
+    fuse_max_planes = int(os.environ.get("EDRL_BF16_FUSE_MAXPLANES", "128"))
     grad_in = staticmethod(lambda dout: ops.to_bf16(dout.contiguous()))
     feat_out = staticmethod(lambda cur: ops.to_f32(cur))
 
@@ -319,6 +324,8 @@ class _TrunkFn(torch.autograd.Function):
             N, H, W, Ci = cur.shape
             s = blk["stride"]
             pl = p[blk["name"] + ".conv1.weight"].shape[0]
+            if pl > K.fuse_max_planes:       # kernel-set policy (see _KBF16)
+                return False
             Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
             if T.kind == "bottleneck":
                 geo = [(H, W, Ci, pl, 1, 1, 0), (H, W, pl, pl, 3, s, 1), (Ho, Wo, pl, 4 * pl, 1, 1, 0)]

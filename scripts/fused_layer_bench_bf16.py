@@ -1,5 +1,5 @@
-"""Per-layer timing of the fused-BatchNorm conv kernels against the separate-pass kernels they replace, on the ResNet-50
-layer shapes (diagnostic, GPU only).  usage: python scripts/fused_layer_bench.py [images] [layer-substring]
+"""bf16 version of scripts/fused_layer_bench.py: per-layer timing of the fused-BatchNorm bf16 conv kernels against the separate-pass
+kernels they replace, on the ResNet-50 layer shapes (diagnostic, GPU only).  usage: python scripts/fused_layer_bench_bf16.py [images] [layer-substring]
 
 columns (ms):  fwd   = plain conv (+stats epilogue)        | fwd+bn = conv that applies BN+ReLU to its input in the operand load
                bnap  = the bn_apply pass on the input tensor that fwd+bn makes unnecessary
@@ -63,34 +63,35 @@ for name, Ci, H, Co, k, s, p, cnt in LAYERS:
     if only and only not in name:
         continue
     Ho = (H + 2 * p - k) // s + 1
-    x = torch.randn(N, H, H, Ci, device=dev)
-    w = torch.randn(Co, k, k, Ci, device=dev) * 0.05
-    dy = torch.randn(N, Ho, Ho, Co, device=dev)
-    yraw = torch.randn(N, Ho, Ho, Co, device=dev)
-    wt = ops.permute_weight(w)
+    x = torch.randn(N, H, H, Ci, device=dev).bfloat16()
+    w32 = torch.randn(Co, k, k, Ci, device=dev) * 0.05
+    w = w32.bfloat16()
+    dy = torch.randn(N, Ho, Ho, Co, device=dev).bfloat16()
+    yraw = torch.randn(N, Ho, Ho, Co, device=dev).bfloat16()
+    wt = ops.permute_weight_bf16(w32)
     flop = 2.0 * N * Ho * Ho * Co * k * k * Ci
     fin, fout, bout = fcoef(Ci), fcoef(Co), bcoef(Co)
     dx = torch.empty_like(x)
     M_in, M_out = N * H * H, N * Ho * Ho
-    t_fwd = timeit(lambda: ops.conv2d_fwd_stats(x, w, None, s, p))
-    t_fwdbn = timeit(lambda: ops.conv2d_fwd_bnin_stats(x, fin, w, s, p))
+    t_fwd = timeit(lambda: ops.conv2d_fwd_bf16(x, w, s, p, stats=True))
+    t_fwdbn = timeit(lambda: ops.conv2d_fwd_bnin_stats_bf16(x, fin, w, s, p))
     act = torch.empty_like(x); mask = torch.empty(M_in, Ci // 4, device=dev, dtype=torch.uint8)
-    t_bnap = timeit(lambda: LL.call("edrl_bn_apply_f32", P(x), P(fin[0]), P(fin[2]), P(fin[3]), None, P(act), P(mask), M_in, Ci, Ci, 1))
+    t_bnap = timeit(lambda: LL.call("edrl_bn_apply_mx", P(x), 1, P(fin[0]), P(fin[2]), P(fin[3]), None, P(act), 1, P(mask), M_in, Ci, 1))
     del act
-    t_dg = timeit(lambda: ops.conv2d_dgrad(dy, wt, tuple(x.shape), s, p, out=dx))
-    t_dgF = timeit(lambda: ops.conv2d_dgrad_bn(dy, yraw, bout, wt, tuple(x.shape), s, p, out=dx))
-    t_dgFE = timeit(lambda: ops.conv2d_dgrad_bn(dy, yraw, bout, wt, tuple(x.shape), s, p, out=dx, ep=(x, None, fin, True)))
+    t_dg = timeit(lambda: ops.conv2d_dgrad_bf16(dy, wt, tuple(x.shape), s, p, out=dx))
+    t_dgF = timeit(lambda: ops.conv2d_dgrad_bn_bf16(dy, yraw, bout, wt, tuple(x.shape), s, p, out=dx))
+    t_dgFE = timeit(lambda: ops.conv2d_dgrad_bn_bf16(dy, yraw, bout, wt, tuple(x.shape), s, p, out=dx, ep=(x, None, fin, True)))
     # separate BN backward on the conv-output-sized tensor
     d_raw = torch.empty_like(dy); dgm = torch.empty(Co, device=dev); dbt = torch.empty(Co, device=dev)
     gam = torch.ones(Co, device=dev); mk = torch.empty(M_out, Co // 4, device=dev, dtype=torch.uint8).fill_(0xf)
     nb = LL.query("edrl_bn_workspace_bytes", M_out, Co) + 2 * Co * 4
     ws = torch.empty(nb // 4, device=dev)
-    t_bnbw = timeit(lambda: LL.call("edrl_bn_bwd_f32", P(dy), None, P(mk), P(yraw), P(fout[0]), P(fout[1]), P(gam), P(dgm), P(dbt), 0,
-                                     P(d_raw), None, 0, M_out, Co, Co, P(ws), nb))
+    t_bnbw = timeit(lambda: LL.call("edrl_bn_bwd_mx", P(dy), 1, P(mk), P(yraw), 1, P(fout[0]), P(fout[1]), P(gam), P(dgm), P(dbt),
+                                     P(d_raw), None, M_out, Co, P(ws), nb))
     del d_raw, ws, mk
-    t_wg = timeit(lambda: ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p))
-    t_wgF = timeit(lambda: ops.conv2d_wgrad_bn(dy, yraw, bout, x, None, tuple(w.shape), s, p))
-    t_wgFX = timeit(lambda: ops.conv2d_wgrad_bn(dy, yraw, bout, x, fin, tuple(w.shape), s, p))
+    t_wg = timeit(lambda: ops.conv2d_wgrad_bf16(dy, x, tuple(w.shape), s, p))
+    t_wgF = timeit(lambda: ops.conv2d_wgrad_bn_bf16(dy, yraw, bout, x, None, tuple(w.shape), s, p))
+    t_wgFX = timeit(lambda: ops.conv2d_wgrad_bn_bf16(dy, yraw, bout, x, fin, tuple(w.shape), s, p))
     sep = t_fwd + t_bnap + t_dg + t_bnbw + t_wg
     fus = t_fwdbn + t_dgFE + t_wgFX
     tot_sep += sep * cnt; tot_fus += fus * cnt
