@@ -1224,7 +1224,7 @@ template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st, const WgradFuse* fuse = nullptr) {
   const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (DYT || XT) ? WG_OCC_FUSED : WG_OCC, FASTLD, DYT, XT, MASKX>;
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (XT ? WG_OCC_FUSED : WG_OCC), FASTLD, DYT, XT, MASKX>;
   WgradFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   static bool attr_set = false;
