@@ -33,11 +33,12 @@ CONFIGS = {
     # Activations of 2 views x 64 x (1 + 32) images exceed 288 GB unless the block outputs are rebuilt in backward (RECOMPUTE).
     "C3": (64, 50, 224, 32, "fp32", "C3: B=64/GPU (global 512 at 8 GPUs), ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32, "
                                     "block outputs recomputed in backward"),
-    # BASELINE.json configs[4] per-GPU shape (an 8-GPU config; B=3 is the largest per-GPU batch whose saved activations
-    # fit 288 GB): 512x512 fundus + 128-slice OCT, second view with the OCT volume dropped (zeros), bf16 encoders.
+    # BASELINE.json configs[4] per-GPU shape (an 8-GPU config; B=4 is the largest per-GPU batch whose saved activations fit
+    # 288 GB without recompute: 203 GiB; B=5 fits with --recompute): 512x512 fundus + 128-slice OCT, second view with the OCT
+    # volume dropped (zeros), bf16 encoders.
     # C1 shapes with the true 3-D-conv OCT encoder (ResNet3D-18 over the 32x224x224 volume)
     "C1-3D": (32, 50, 224, 32, "fp32", "C1-3D: B=32/GPU, ResNet-50 fundus encoder + ResNet3D-18 OCT volume encoder, 224x224 fundus + 32-slice OCT, fp32"),
-    "C4": (3, 50, 512, 128, "bf16", "C4: B=3/GPU, ResNet-50 bf16 encoders, 512x512 fundus + 128-slice OCT, OCT-dropped second view"),
+    "C4": (4, 50, 512, 128, "bf16", "C4: B=4/GPU, ResNet-50 bf16 encoders, 512x512 fundus + 128-slice OCT, OCT-dropped second view"),
 }
 RECOMPUTE = {"C3"}     # configs that run with args.activation_recompute (encoders.ResNetTrunk.recompute_out)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz

@@ -169,6 +169,20 @@ int edrl_bn_bwd_finalize_partials_f32(const float* part, long nchunks, int plane
                                       const float* fcoef, float* dgamma, float* dbeta, float* bcoef, double* group_ws,
                                       size_t group_ws_bytes, hipStream_t stream);
 
+/* Stem (conv 7x7/s2 -> BatchNorm -> ReLU -> max-pool 3x3/s2/p1, the head of the encoder slots behind fusion_net.py:884-885) with
+ * the BatchNorm + ReLU folded into the max-pool: the activated stem tensor and its sign bytes are never stored.
+ * x = RAW stem conv output [N,H,W,C]; fcoef [5][C] from edrl_bn_train_stats_fcoef_f32; backward = _reduce (partial sums, planes = 3
+ * for edrl_bn_bwd_finalize_partials_f32) then _apply (d_raw = A*g + nK2*x + C2 for the stem weight gradient). */
+int edrl_bn_train_stats_fcoef_f32(const float* x, long M, int C, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, float* fcoef, float* workspace,
+                                  size_t workspace_bytes, hipStream_t stream);
+int edrl_maxpool3x3s2_bn_fwd_f32(const float* x, const float* fcoef, float* y, unsigned char* idx, int N, int H, int W, int C,
+                                 hipStream_t stream);
+int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef, float* part,
+                                        size_t part_bytes, int N, int H, int W, int C, hipStream_t stream);
+int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef,
+                                       const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t stream);
+
 /* bf16 counterparts of the fused-BatchNorm entry points (conv_bf16.hip / bn_pool.hip): bf16 tensors, fp32 coefficient arrays
  * fcoef [5][C] / bcoef [4][C] and fp32 partial sums; same contracts as the _f32 versions above.  Ci % 32 == 0, Co % 32 == 0. */
 int edrl_conv2d_fused_ok_bf16(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad);

@@ -122,19 +122,19 @@ def trunk_forward_bf16(x, sd, kind, blocks):
     return x
 
 
-def fundus_encoder_forward(x, sd, kind, blocks, proj_w, proj_b, train=True):
-    """[B,3,H,W] -> (tokens [B,N2,D], pooled)."""
-    f = trunk_forward(x, sd, kind, blocks, train)
+def fundus_encoder_forward(x, sd, kind, blocks, proj_w, proj_b, train=True, pins=None):
+    """[B,3,H,W] -> (tokens [B,N2,D], pooled).  pins: see trunk_forward."""
+    f = trunk_forward(x, sd, kind, blocks, train, pins=pins)
     B, C, h, w = f.shape
     tok = f.permute(0, 2, 3, 1).reshape(B, h * w, C)
     tokens = F.linear(tok, proj_w, proj_b)
     return tokens, tokens.mean(1)
 
 
-def oct_encoder_forward(x, sd, kind, blocks, proj_w, proj_b, train=True):
-    """[B,1,S,H,W] -> (tokens [B,S,D], pooled)."""
+def oct_encoder_forward(x, sd, kind, blocks, proj_w, proj_b, train=True, pins=None):
+    """[B,1,S,H,W] -> (tokens [B,S,D], pooled).  pins: see trunk_forward."""
     B, C, S, H, W = x.shape
-    f = trunk_forward(x.reshape(B * S, 1, H, W), sd, kind, blocks, train)
+    f = trunk_forward(x.reshape(B * S, 1, H, W), sd, kind, blocks, train, pins=pins)
     pooled = f.mean(dim=(2, 3)).reshape(B, S, -1)
     tokens = F.linear(pooled, proj_w, proj_b)
     return tokens, tokens.mean(1)
@@ -192,3 +192,15 @@ def trunk3d_state(trunk, dtype=torch.float64, requires_grad=True):
     for n, b in trunk.named_buffers():
         sd[n] = b.detach().cpu().to(dtype) if b.dtype.is_floating_point else b.detach().cpu().clone()
     return sd
+
+
+def pins_from_capture(cap):
+    """Discrete decisions of one product trunk pass (ResNetTrunk._capture record) in the form trunk_forward(pins=...) takes:
+    ReLU sign bits per conv unit (NCHW bool) and the max-pool arg-max taps."""
+    pins = {}
+    for name, rec in cap.items():
+        if name.startswith("bwd:") or name == "maxpool" or not rec["relu"]:
+            continue
+        pins[name] = (rec["out"].detach().permute(0, 3, 1, 2).cpu() > 0)
+    pins["maxpool"] = cap["maxpool"]["idx"].permute(0, 3, 1, 2).cpu()
+    return pins

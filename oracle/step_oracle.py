@@ -43,18 +43,21 @@ class OracleEDRL:
             out[f"{key}.token_proj.bias"] = e["b"]
         return out
 
-    def forward(self, X, y, noise):
+    def forward(self, X, y, noise, pins=None):
+        """pins (optional): (fundus pins, oct pins) = the product's ReLU / max-pool decisions of this view's encoder passes
+        (resnet_oracle.pins_from_capture), which take the ill-conditioned sign bits out of a gradient comparison."""
         f, o = self.enc["transformer_2DNet"], self.enc["transformer_3DNet"]
-        x, _ = RO.fundus_encoder_forward(X[0].to(self.dtype), f["sd"], f["kind"], f["blocks"], f["w"], f["b"])
-        x1, _ = RO.oct_encoder_forward(X[1].to(self.dtype), o["sd"], o["kind"], o["blocks"], o["w"], o["b"])
+        pf, po = pins if pins is not None else (None, None)
+        x, _ = RO.fundus_encoder_forward(X[0].to(self.dtype), f["sd"], f["kind"], f["blocks"], f["w"], f["b"], pins=pf)
+        x1, _ = RO.oct_encoder_forward(X[1].to(self.dtype), o["sd"], o["kind"], o["blocks"], o["w"], o["b"], pins=po)
         return O.medfusion_forward_tokens(self.p, self.state, x, x1, y, noise, self.batch_size)
 
-    def train_step(self, data, y, noise1, noise2, lr=None, adam_state=None):
+    def train_step(self, data, y, noise1, noise2, lr=None, adam_state=None, pins=None):
         params = self.parameters()
         for t in params.values():
             t.grad = None
-        pred, loss, cf1, aux = self.forward(data[0], y, noise1)
-        _, _, cf2, _ = self.forward(data[1], y, noise2)
+        pred, loss, cf1, aux = self.forward(data[0], y, noise1, None if pins is None else pins[0])
+        _, _, cf2, _ = self.forward(data[1], y, noise2, None if pins is None else pins[1])
         loss_mdd = O.MK_MMD(cf1, cf2)
         total = loss + loss_mdd
         total.backward()

@@ -604,6 +604,149 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v4_kernel(const T* __res
   }
 }
 
+// ---- stem: BatchNorm + ReLU folded into the 3x3/s2 max-pool (the stem's activated tensor, 64 x 112^2 per 224^2 image, and its
+// sign bytes are never stored).  Forward: y = max over the window of relu(x*scale + shift2) on the RAW stem conv output; idx as in
+// maxpool3x3s2_fwd (first maximum in scan order).  Backward, two kernels that both rebuild the max-pool gradient on the fly
+// (gather form: an input pixel collects dy of every window whose arg-max tap points at it) and the ReLU decision from the raw
+// tensor: MODE 0 reduces (sum g, sum g*xhat) per 1024-pixel chunk [chunk][3][C] (colstat layout), MODE 1 writes
+// d_raw = A*g + nK2*x + C2.  fcoef [5][C], bcoef [4][C] as in the fused conv kernels.
+__global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ fcoef,
+                                                             float* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
+                                                             int W, int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool any = false;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = ho * 2 - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = wo * 2 - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        const f32x4 v = edrl_bn_relu2(*reinterpret_cast<const f32x4*>(x + (((long)n * H + h) * W + w) * C + c), sc, sh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (!any || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
+        any = true;
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = best;
+    *reinterpret_cast<unsigned int*>(idx + i * 4) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+  }
+}
+
+__device__ __forceinline__ f32x4 maxpool_bn_gather_g(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                     const f32x4 xr, const f32x4 sc, const f32x4 sh, int n, int h, int w, int c,
+                                                     int C, int Ho, int Wo) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int th = h + 1 - kh;
+    if (th < 0 || (th & 1)) continue;
+    const int ho = th >> 1;
+    if (ho >= Ho) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int tw = w + 1 - kw;
+      if (tw < 0 || (tw & 1)) continue;
+      const int wo = tw >> 1;
+      if (wo >= Wo) continue;
+      const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
+      const unsigned m = *reinterpret_cast<const unsigned int*>(idx + o);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+      const unsigned tap = (unsigned)(kh * 3 + kw);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (((m >> (8 * e)) & 0xff) == tap) s[e] += g[e];
+    }
+  }
+  const f32x4 pre = edrl_bn_pre2(xr, sc, sh);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = pre[e] > 0.f ? s[e] : 0.f;
+  return s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                             const float* __restrict__ x, const float* __restrict__ fcoef,
+                                                             const float* __restrict__ bcoef, float* __restrict__ part,
+                                                             float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+  // MODE 0: grid (chunks of BN_ROWS_PER_CHUNK pixels, C/256 column blocks), reduction as colstat_kernel<1>
+  // MODE 1: grid-stride elementwise
+  const int C4 = C >> 2;
+  const long M = (long)N * H * W;
+  if (MODE == 1) {
+    const long total = M * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const long r = i / C4;
+      const int c = (int)(i - r * C4) * 4;
+      const int w = (int)(r % W);
+      const long t = r / W;
+      const int h = (int)(t % H), n = (int)(t / H);
+      const f32x4 xr = *reinterpret_cast<const f32x4*>(x + r * C + c);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c);
+      const f32x4 g = maxpool_bn_gather_g(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo);
+      const f32x4 A = *reinterpret_cast<const f32x4*>(bcoef + c);
+      const f32x4 nK2 = *reinterpret_cast<const f32x4*>(bcoef + (long)C + c);
+      const f32x4 C2 = *reinterpret_cast<const f32x4*>(bcoef + 2 * (long)C + c);
+      *reinterpret_cast<f32x4*>(dx + r * C + c) = edrl_bn_bwd_dx2(g, xr, A, nK2, C2);
+    }
+    return;
+  }
+  __shared__ float sh_[256 * 8];
+  const int CG = C4 < 64 ? C4 : 64;
+  const int RL = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, rl = tid / CG;
+  const int c = (blockIdx.y * 64 + cg) * 4;
+  const long row0 = (long)blockIdx.x * BN_ROWS_PER_CHUNK;
+  long row1 = row0 + BN_ROWS_PER_CHUNK;
+  if (row1 > M) row1 = M;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (c < C && rl < RL) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(fcoef + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(fcoef + (long)C + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c);
+    for (long r = row0 + rl; r < row1; r += RL) {
+      const int w = (int)(r % W);
+      const long t = r / W;
+      const int h = (int)(t % H), n = (int)(t / H);
+      const f32x4 xr = *reinterpret_cast<const f32x4*>(x + r * C + c);
+      const f32x4 g = maxpool_bn_gather_g(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo);
+      s0 += g;
+      s1 += g * ((xr - mu) * rs);
+    }
+  }
+  float* my = sh_ + tid * 8;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { my[e] = s0[e]; my[4 + e] = s1[e]; }
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int q = 0; q < RL; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += sh_[(q * CG + cg) * 8 + e];
+    float* p = part + (long)blockIdx.x * 3 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[c + e] = a[e]; p[C + c + e] = a[4 + e]; }
+  }
+}
+
 // [N][C][H][W] -> [N][H][W][Cp] (channels >= C zero filled)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            int N, int C, int H, int W, int Cp) {
@@ -1098,6 +1241,58 @@ int edrl_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* 
   else
     hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, st, dy, idx, dx, N,
                        H, W, C, Ho, Wo);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Stem: BatchNorm(train) statistics of x [M][C] as ONE coefficient array fcoef [5][C] (edrl_bn_train_stats_f32 otherwise).
+int edrl_bn_train_stats_fcoef_f32(const float* x, long M, int C, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, float* fcoef, float* workspace,
+                                  size_t workspace_bytes, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3) || !fcoef) return EDRL_EINVAL;
+  if (workspace_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
+  const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL((colstat_kernel<0, float, float>), dim3(chunks, edrl_cdiv(C, 256)), dim3(256), 0, st, x,
+                     (const float*)nullptr, (const float*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, M, C, (long)C, workspace);
+  EDRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M,
+                     BN_ROWS_PER_CHUNK, gamma, beta, running_mean, running_var, momentum, eps, fcoef, fcoef + C,
+                     fcoef + 2 * (long)C, fcoef + 3 * (long)C, fcoef + 4 * (long)C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+// Stem max-pool with the BatchNorm + ReLU of its input folded in (x = RAW stem conv output [N,H,W,C], fcoef [5][C]):
+// y [N,Ho,Wo,C] = maxpool3x3/s2/p1(relu(x*scale + shift2)), idx = arg-max tap bytes.
+int edrl_maxpool3x3s2_bn_fwd_f32(const float* x, const float* fcoef, float* y, unsigned char* idx, int N, int H, int W, int C,
+                                 hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef) return EDRL_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bn_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, fcoef, y, idx, N, H,
+                     W, C, Ho, Wo);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+// Its backward in two launches (the max-pool gradient and the ReLU decision are rebuilt on the fly in both):
+//   _reduce: partial sums (sum g, sum g*xhat) -> part [ceil(N*H*W/1024)][3][C] (planes = 3 for edrl_bn_bwd_finalize_partials_f32)
+//   _apply : d_raw [N,H,W,C] = A*g + nK2*x + C2 with bcoef [4][C]
+int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef, float* part,
+                                        size_t part_bytes, int N, int H, int W, int C, hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !part) return EDRL_EINVAL;
+  const long M = (long)N * H * W;
+  if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bn_bwd_kernel<0>, dim3(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256)), dim3(256), 0, st, dy, idx, x,
+                     fcoef, (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef,
+                                       const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !bcoef || !d_raw) return EDRL_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bn_bwd_kernel<1>, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, st, dy, idx, x, fcoef, bcoef,
+                     (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

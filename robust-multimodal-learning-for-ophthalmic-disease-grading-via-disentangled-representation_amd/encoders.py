@@ -115,6 +115,7 @@ def _bn_bwd(dout, mask, raw, mean, rstd, gamma, want_dres):
 # A block whose layer geometries lack the fused fast paths (edrl_conv2d_fused_ok_f32: tiny / odd maps) keeps the separate
 # passes; the gradient handed from block to block is ("plain", dout) or ("masked", g, part, chunks, planes).
 _FUSE_BN = os.environ.get("EDRL_FUSE_BN", "1") != "0"
+_FUSE_STEM = os.environ.get("EDRL_FUSE_STEM", "1") != "0"      # BatchNorm + ReLU of the stem folded into its max-pool (fp32 trunk)
 
 
 def _fcoef_from_partials(part, chunks, M, C, bn):
@@ -188,6 +189,28 @@ class _K32:
     @staticmethod
     def stem_fwd(T, x, p, bnd, cap, cb):
         folded = False
+        if _STEM_S2D and _FUSE_STEM and not x.requires_grad:
+            # conv (4x4 over the space-to-depth image) -> statistics -> max-pool that applies BN+ReLU to its input on the fly:
+            # the activated stem tensor (64 x 112^2 per 224^2 image) and its sign bytes are never stored
+            raw, x_keep, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
+            bn = bnd("bn1", p)
+            N, H, W, C = raw.shape
+            M = N * H * W
+            fc = torch.empty((5, C), device=x.device, dtype=torch.float32)
+            ws, nbytes = _bn_ws(M, C, x.device)
+            L.call("edrl_bn_train_stats_fcoef_f32", P(raw), M, C, P(bn["weight"]), P(bn["bias"]), P(bn["running_mean"]),
+                   P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(fc), P(ws), nbytes)
+            Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            p0 = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+            idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+            ops.call_timed_bytes("maxpool_bn_fwd", M * C * 4.0 + p0.numel() * 5.0, "edrl_maxpool3x3s2_bn_fwd_f32", P(raw), P(fc), P(p0),
+                                 P(idx), N, H, W, C)
+            if cap is not None:
+                a0 = _dbg_act(raw, fc)
+                cap["conv1"] = dict(bn="bn1", inp=x, stride=2, pad=3, relu=True, residual=None, raw=raw, out=a0, mean=fc[0],
+                                    rstd=fc[1], mask=None, fused=True)
+                cap["maxpool"] = dict(inp=a0, out=p0, idx=idx, fused=True)
+            return p0, ("fused", x_keep, folded, raw, fc, idx)
         if _STEM_S2D and not x.requires_grad:        # as a 4x4 conv over the space-to-depth image (ops.stem_conv_fwd)
             raw, x_keep, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
             a0, m0, r0, k0 = _bn_fwd(raw, bnd("bn1", p), True)
@@ -208,6 +231,27 @@ class _K32:
 
     @staticmethod
     def stem_bwd(T, stem, p, dcur, grads, cap, bn_bwd, conv_bwd, needs_x):
+        if stem[0] == "fused":
+            _, x, folded, raw, fc, idx = stem
+            N, H, W, C = raw.shape
+            M = N * H * W
+            ws, nbytes = _bn_ws(M, C, raw.device)
+            ops.call_timed_bytes("maxpool_bn_bwd", M * C * 4.0 + dcur.numel() * 5.0, "edrl_maxpool3x3s2_bn_bwd_reduce_f32", P(dcur),
+                                 P(idx), P(raw), P(fc), P(ws), nbytes, N, H, W, C)
+            bc, dg, db = _bcoef_from_partials(ws, (M + 1023) // 1024, 3, M, p["bn1.weight"], fc)
+            grads["bn1.weight"], grads["bn1.bias"] = dg, db
+            draw = torch.empty_like(raw)
+            ops.call_timed_bytes("maxpool_bn_bwd", M * C * 8.0 + dcur.numel() * 5.0, "edrl_maxpool3x3s2_bn_bwd_apply_f32", P(dcur),
+                                 P(idx), P(raw), P(fc), P(bc), P(draw), N, H, W, C)
+            grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), folded)
+            if cap is not None:
+                da0 = torch.empty_like(raw)
+                L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
+                cap["maxpool"].update(dout=dcur, dinp=da0)
+                g0 = da0 * (torch.addcmul(fc[4], raw, fc[2]) > 0)
+                cap["bwd:bn1"] = dict(dout=g0, dgamma=dg, dbeta=db, d_raw=draw, dres=None, masked=True)
+                cap["conv1"].update(d_raw=draw, dW=grads["conv1.weight"], dx_before=None, dx_after=None)
+            return None
         x, folded, raw, a0_shape, m0, r0, k0, idx = stem
         N, H, W, C = a0_shape
         da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.float32)
@@ -294,6 +338,9 @@ class _TrunkFn(torch.autograd.Function):
         saved = {}
         x = ops._chk(x, "encoder input")
         cap = T._capture     # None, or a dict filled with every layer's operands/results (tests/test_gpu_layerwise.py)
+        if T._capture_seq is not None:      # one fresh record per forward pass (the two views of a step: tests/test_gpu_head.py)
+            cap = {}
+            T._capture_seq.append(cap)
         T._wt_cache = {}     # permuted weights are shared by the backward passes that follow this forward
 
         def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
@@ -705,6 +752,7 @@ class ResNetTrunk(nn.Module):
         self.out_channels = inpl
         self.param_names = [n for n, _ in self.named_parameters()]
         self._capture = None
+        self._capture_seq = None
         self._wt_cache = {}
         self.kernels = _KBF16 if dtype == "bf16" else _K32
         self._register_state_dict_hook(self._save_hook)
