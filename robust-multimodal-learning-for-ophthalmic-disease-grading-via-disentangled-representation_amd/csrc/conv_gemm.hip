@@ -238,6 +238,23 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
 // K index advances incrementally (no integer division in the loop).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// 16-byte buffer store whose row advance rides in the scalar offset (no VALU per store).  gfx950 keeps reading the four data
+// registers for a few cycles after issue; the compiler's hazard table covers that only for the immediate-offset form, and with
+// an SGPR offset it schedules a VALU write to the first data register directly behind the store (observed: the written value
+// lands in memory for part of the wave).  The store and the wait states are therefore one asm block.
+__device__ __forceinline__ u32x4 edrl_rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void edrl_buffer_store_b128_soff(f32x4 v, u32x4 rs, unsigned voff, int soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 4" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
 // BUF (FAST only; host-checked footprints < 2 GiB): both operands come through buffer descriptors -- the gathered one
 // through a per-workgroup descriptor based at the first image the tile's rows touch -- so masked rows / taps are an
 // out-of-range 32-bit offset that the range check zero-fills: no 64-bit address arithmetic, no selects on the address
@@ -287,9 +304,10 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const long m = m0 + r0 + RPP * i;
     if (m < g.M) {
       const int ohw = g.OHs * g.OWs;
-      const int n = (int)(m / ohw);
-      const int rem = (int)(m - (long)n * ohw);
-      const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+      const int n = (int)(((unsigned long long)(unsigned)m * g.mg_ohw) >> g.sh_ohw);      // m / ohw (GatherGeom: magic division)
+      const int rem = (int)m - n * ohw;
+      const int ii = (int)(((unsigned long long)(unsigned)rem * g.mg_ow) >> g.sh_ow);     // rem / OWs
+      const int jj = rem - ii * g.OWs;
       const int oh = g.h0 + ii * g.step, ow = g.w0 + jj * g.step;
       rn[i] = n;
       if (DGRAD) { rh[i] = oh + g.pad; rw[i] = ow + g.pad; }
@@ -321,8 +339,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   if constexpr (BUF) {
     const int ohw = g.OHs * g.OWs;
     long mlast = m0 + BM; if (mlast > g.M) mlast = g.M;
-    n_first = (int)(m0 / ohw);
-    const int n_last = (int)((mlast - 1) / ohw);
+    n_first = (int)(((unsigned long long)(unsigned)m0 * g.mg_ohw) >> g.sh_ohw);
+    const int n_last = (int)(((unsigned long long)(unsigned)(mlast - 1) * g.mg_ohw) >> g.sh_ohw);
     const unsigned a_bytes = (unsigned)(((long)(n_last - n_first + 1) * g.SH * g.SW - 1) * g.ld_src * 4 + (long)g.SC * 4);
     rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
     rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, (int)((long)g.NC * g.Kfull * 4), 0x00020000);
@@ -583,12 +601,110 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
     // EPI 1: BatchNorm(+ReLU) backward of the tensor this tile is the gradient of (channels n .. n+3 of this lane)
     f32x4 e_scale = zero4, e_shift2 = zero4;
-    if constexpr (EPI == 1) {
+    if constexpr (EPI != 0) {
       if (n < g.NC && !F.ep_mask) {
         e_scale = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + n);
         e_shift2 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + n);
       }
     }
+    // Lean path (every row of the tile valid, no bias / ReLU / multiplier, destination pixel = row): next to the fp32 MFMA
+    // every VALU instruction is matrix-pipe time taken from the other workgroups of the CU, so the stores (and the EPI operand
+    // loads) go through per-wave buffer descriptors -- lane offset fixed, the row advance in the scalar offset, the column
+    // guard an out-of-range lane offset -- the loads of a 32-row pass are all issued before its LDS transpose, and the only
+    // vector work per row group is the arithmetic itself.  Specialised (no per-row-group branches):
+    //   EPI 0: plain store (+ BatchNorm statistics), no accumulate
+    //   EPI 1: ReLU decision recomputed from ep_x (GF_EPI_RELU), no accumulate      (data gradients inside a block)
+    //   EPI 2: sign bytes, accumulate into dst                                     (block-input gradient)
+    // every other combination takes the general loop below.
+    const bool lean_flags = EPI == 0 ? !accum
+                          : EPI == 1 ? (!accum && !F.ep_mask && (g.flags & GF_EPI_RELU))
+                                     : (accum && F.ep_mask != nullptr);
+    const bool lean = m0 + BM <= g.M && !bias && !mul && !relu && lean_flags && !(DGRAD && g.step > 1);
+    if (lean) {
+      constexpr unsigned OOBE = 0x80000000u;
+      constexpr int NT = 32 / RPP2;                         // row groups per 32-row pass
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const long row0 = m0 + (long)(wv >> 1) * WM;
+      const int col0 = n0 + (wv & 1) * WN;
+      const bool colok = n < g.NC;
+      const __amdgpu_buffer_rsrc_t rs_d =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(dst + row0 * g.ld_dst + col0), 0, (int)(WM * g.ld_dst * 4), 0x00020000);
+      const u32x4 ws_d = edrl_rsrc_words(dst + row0 * g.ld_dst + col0, (unsigned)(WM * g.ld_dst * 4));   // same descriptor, for the asm store
+      const unsigned vd = colok ? (unsigned)((srow * (int)g.ld_dst + sc4 * 4) * 4) : OOBE;
+      const int rstep_d = RPP2 * (int)g.ld_dst * 4;          // bytes per row group
+      __amdgpu_buffer_rsrc_t rs_x, rs_k;
+      unsigned vx = 0, vk = 0;
+      int rstep_x = 0, rstep_k = 0;
+      f32x4 xr[EPI != 0 ? NT : 1], old[EPI == 2 ? NT : 1];
+      int kb[EPI == 2 ? NT : 1];
+      if constexpr (EPI != 0) {
+        rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)F.ep_x + row0 * F.ld_ep + col0), 0, (int)(WM * F.ld_ep * 4),
+                                                 0x00020000);
+        vx = colok ? (unsigned)((srow * (int)F.ld_ep + sc4 * 4) * 4) : OOBE;
+        rstep_x = RPP2 * (int)F.ld_ep * 4;
+      }
+      if constexpr (EPI == 2) {
+        const int nq = g.NC >> 2;
+        rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)(F.ep_mask + row0 * nq + (col0 >> 2)), 0, WM * nq, 0x00020000);
+        vk = colok ? (unsigned)(srow * nq + sc4) : OOBE;
+        rstep_k = RPP2 * nq;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (EPI != 0) {       // all operand loads of the pass in flight together: one memory latency per pass
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            xr[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vx, (i * NT + t) * rstep_x, 0));
+            if constexpr (EPI == 2) {
+              old[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)vd, (i * NT + t) * rstep_d, 0));
+              kb[t] = __builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)vk, (i * NT + t) * rstep_k, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(stage + sc4 * 4);
+        if (EPI == 0 && stats) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (t * RPP2 + srow) * SLD + sc4 * 4);
+            const f32x4 d = v - kshift;
+            st0 += d;
+            st1 = __builtin_elementwise_fma(d, d, st1);
+            edrl_buffer_store_b128_soff(v, ws_d, vd, (i * NT + t) * rstep_d);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + (t * RPP2 + srow) * SLD + sc4 * 4);
+            if constexpr (EPI == 1) {
+              const f32x4 pre = edrl_bn_pre2(xr[t], e_scale, e_shift2);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = pre[e] > 0.f ? v[e] : 0.f;
+            }
+            if constexpr (EPI == 2) {
+              v += old[t];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {    // bit e of the sign byte -> all-ones / zero (1-bit signed field extract), AND
+                const float ve = v[e];         // (a copy: bit_cast applied to the vector element itself reads element 0)
+                v[e] = __int_as_float(__float_as_int(ve) & ((kb[t] << (31 - e)) >> 31));
+              }
+            }
+            if constexpr (EPI != 0) {
+              st0 += v;
+              st1 = __builtin_elementwise_fma(v, xr[t], st1);
+            }
+            edrl_buffer_store_b128_soff(v, ws_d, vd, (i * NT + t) * rstep_d);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -624,7 +740,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
           if (mul) v *= *reinterpret_cast<const f32x4*>(mul + pix * g.ld_aux + n);
           float* p = dst + pix * g.ld_dst + n;
           if (accum) v += *reinterpret_cast<const f32x4*>(p);
-          if constexpr (EPI == 1) {
+          if constexpr (EPI != 0) {
             const f32x4 xr = *reinterpret_cast<const f32x4*>((const float*)F.ep_x + pix * F.ld_ep + n);
             if (F.ep_mask) {
               const int mb = F.ep_mask[pix * (long)(g.NC >> 2) + (n >> 2)];
@@ -643,7 +759,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // staging reads done before the next pass overwrites them
     }
-    if constexpr (EPI == 1) {
+    if constexpr (EPI != 0) {
       // (sum g, sum g*x) of the tile's valid rows -> F.ep_part[chunk0 + tile_m][2][NC]
 #pragma unroll
       for (int o = 32; o >= C4; o >>= 1) {
@@ -752,7 +868,9 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   }
   GatherFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, g, tiles_n, F);
+  GatherGeom gm = g;
+  gather_geom_magic(&gm);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, gm, tiles_n, F);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
@@ -1563,8 +1681,11 @@ int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g_in, const float* yraw, const fl
       // (zero fill, or mask + reduce the accumulated gradient)
       if (g.Ktot == 0 && (flags & GF_ACCUM) && !ep_raw) continue;
       F.ep_chunk0 = chunk0;
-      const int rc = ep_raw ? dispatch_gather_fused<true, 2, 1>(g_in, wt, dx, g, F, st)
-                            : dispatch_gather_fused<true, 2, 0>(g_in, wt, dx, g, F, st);
+      // EPI 2 = the instantiation whose lean epilogue is specialised for (sign bytes, accumulate); EPI 1 for (recomputed
+      // ReLU decision, no accumulate); both carry the general epilogue for every other combination
+      const int rc = !ep_raw ? dispatch_gather_fused<true, 2, 0>(g_in, wt, dx, g, F, st)
+                     : (ep_mask && (flags & GF_ACCUM)) ? dispatch_gather_fused<true, 2, 2>(g_in, wt, dx, g, F, st)
+                                                       : dispatch_gather_fused<true, 2, 1>(g_in, wt, dx, g, F, st);
       if (rc) return rc;
       chunk0 += (g.M + 127) / 128;
     }

@@ -25,7 +25,24 @@ struct GatherGeom {
   // partial layout of bn_pool.hip, so the BN statistics need no extra pass over the conv output.
   float* stat_part;
   const float* stat_shift;
+  // Division of a row index (< 2^31) by OHs*OWs and by OWs as multiply-high + shift: q = (n * mg) >> sh with sh = 31 + ceil(log2 d),
+  // mg = ceil(2^sh / d) (exact for n < 2^31).  Filled by the launcher (gather_geom_magic); replaces ~100-instruction software
+  // divisions in the row decode of every workgroup.
+  unsigned mg_ohw, mg_ow;
+  int sh_ohw, sh_ow;
 };
+
+static inline void gather_magic(unsigned d, unsigned* mg, int* sh) {
+  int l = 0;
+  while ((1ull << l) < d) ++l;
+  *sh = 31 + l;
+  *mg = (unsigned)(((1ull << *sh) + d - 1) / d);
+}
+static inline void gather_geom_magic(GatherGeom* g) {
+  const long ohw = (long)g->OHs * g->OWs;
+  gather_magic(ohw > 0 && ohw < (1L << 31) ? (unsigned)ohw : 1u, &g->mg_ohw, &g->sh_ohw);
+  gather_magic(g->OWs > 0 ? (unsigned)g->OWs : 1u, &g->mg_ow, &g->sh_ow);
+}
 
 // Fused-BatchNorm operands of the gather kernels (conv_gather_*_kernel<..., ATR, EPI>).
 struct GatherFuse {

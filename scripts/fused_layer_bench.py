@@ -4,7 +4,8 @@ layer shapes (diagnostic, GPU only).  usage: python scripts/fused_layer_bench.py
 columns (ms):  fwd   = plain conv (+stats epilogue)        | fwd+bn = conv that applies BN+ReLU to its input in the operand load
                bnap  = the bn_apply pass on the input tensor that fwd+bn makes unnecessary
                dg    = plain data gradient                   | dgF = d_raw formed in the operand load | dgFE = dgF + masked
-                       gradient + BN-backward partial sums from the epilogue
+                       gradient + BN-backward partial sums from the epilogue (ReLU decision recomputed: gradients inside a block)
+                       | dgFA = dgFE with sign bytes, accumulating into dx (the block-input gradient)
                bnbw  = the colstat + bn_bwd_apply passes (on the conv-output-sized tensor) that dgF/wgF make unnecessary
                wg    = plain weight gradient                 | wgF = d_raw in the dY load | wgFX = wgF + BN+ReLU in the X load
 """
@@ -56,7 +57,7 @@ def bcoef(C):
     return bc
 
 
-hdr = f"{'layer':20s} {'GFLOP':>7s} | {'fwd':>6s} {'fwd+bn':>6s} {'bnap':>6s} | {'dg':>6s} {'dgF':>6s} {'dgFE':>6s} {'bnbw':>6s} | {'wg':>6s} {'wgF':>6s} {'wgFX':>6s} | sep -> fused (ms, x count)"
+hdr = f"{'layer':20s} {'GFLOP':>7s} | {'fwd':>6s} {'fwd+bn':>6s} {'bnap':>6s} | {'dg':>6s} {'dgF':>6s} {'dgFE':>6s} {'dgFA':>6s} {'bnbw':>6s} | {'wg':>6s} {'wgF':>6s} {'wgFX':>6s} | sep -> fused (ms, x count)"
 print(hdr)
 tot_sep = tot_fus = 0.0
 for name, Ci, H, Co, k, s, p, cnt in LAYERS:
@@ -80,6 +81,11 @@ for name, Ci, H, Co, k, s, p, cnt in LAYERS:
     t_dg = timeit(lambda: ops.conv2d_dgrad(dy, wt, tuple(x.shape), s, p, out=dx))
     t_dgF = timeit(lambda: ops.conv2d_dgrad_bn(dy, yraw, bout, wt, tuple(x.shape), s, p, out=dx))
     t_dgFE = timeit(lambda: ops.conv2d_dgrad_bn(dy, yraw, bout, wt, tuple(x.shape), s, p, out=dx, ep=(x, None, fin, True)))
+    kbytes = torch.randint(0, 16, (M_in, Ci // 4), device=dev, dtype=torch.uint8)
+    dx.zero_()
+    t_dgFA = timeit(lambda: ops.conv2d_dgrad_bn(dy, yraw, bout, wt, tuple(x.shape), s, p, out=dx, accumulate=True,
+                                                ep=(x, kbytes, fin, True)))
+    del kbytes
     # separate BN backward on the conv-output-sized tensor
     d_raw = torch.empty_like(dy); dgm = torch.empty(Co, device=dev); dbt = torch.empty(Co, device=dev)
     gam = torch.ones(Co, device=dev); mk = torch.empty(M_out, Co // 4, device=dev, dtype=torch.uint8).fill_(0xf)
@@ -94,7 +100,7 @@ for name, Ci, H, Co, k, s, p, cnt in LAYERS:
     sep = t_fwd + t_bnap + t_dg + t_bnbw + t_wg
     fus = t_fwdbn + t_dgFE + t_wgFX
     tot_sep += sep * cnt; tot_fus += fus * cnt
-    print(f"{name:20s} {flop/1e9:7.1f} | {t_fwd:6.3f} {t_fwdbn:6.3f} {t_bnap:6.3f} | {t_dg:6.3f} {t_dgF:6.3f} {t_dgFE:6.3f} {t_bnbw:6.3f} | "
+    print(f"{name:20s} {flop/1e9:7.1f} | {t_fwd:6.3f} {t_fwdbn:6.3f} {t_bnap:6.3f} | {t_dg:6.3f} {t_dgF:6.3f} {t_dgFE:6.3f} {t_dgFA:6.3f} {t_bnbw:6.3f} | "
           f"{t_wg:6.3f} {t_wgF:6.3f} {t_wgFX:6.3f} | {sep:6.3f} -> {fus:6.3f} x{cnt}", flush=True)
     del x, w, dy, yraw, wt, dx
 print(f"R50 body per {N} images (one conv+BN unit = fwd + bn_apply(in) + dgrad + bn_bwd(out) + wgrad): separate {tot_sep:.1f} ms -> fused {tot_fus:.1f} ms")
