@@ -1022,9 +1022,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   const int tyi = trem / g.tiles_x;
   const int co0 = tyi * BM, n0 = (trem - tyi * g.tiles_x) * BN;
 
-  const long ptiles = (g.P + BKT - 1) / BKT;
-  const long t_begin = (long)split * g.tiles_per_split;
-  long t_end = t_begin + g.tiles_per_split;
+  const int ptiles = (int)((g.P + BKT - 1) / BKT);             // (P < 2^31: host-checked)
+  const int t_begin = split * g.tiles_per_split;
+  int t_end = t_begin + g.tiles_per_split;
   if (t_end > ptiles) t_end = ptiles;
 
   // fixed column decode for the im2col operand
@@ -1045,31 +1045,35 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   if (VEC) {
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      const long p = t_begin * BKT + (tid + 256 * i) / BC4;
+      const long p = (long)t_begin * BKT + (tid + 256 * i) / BC4;
       bp[i] = p;
       const long n = p / ohw;
       const int rem = (int)(p - n * ohw);
       bn_[i] = (int)n; boh[i] = rem / g.OW; bow[i] = rem - boh[i] * g.OW;
     }
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) ap[i] = t_begin * BKT + (tid + 256 * i) / AC4;
+    for (int i = 0; i < A_LD; ++i) ap[i] = (long)t_begin * BKT + (tid + 256 * i) / AC4;
   }
   // ---- FASTLD state
   constexpr unsigned OOB = 0x80000000u;         // offsets at/above 2 GiB stay outside every descriptor (ranges < 2 GiB)
-  unsigned a_off[A_LD], b_roff[B_LD];
-  int b_ih[B_LD], b_iw[B_LD];
-  int ih_lim = 0, iw_lim = 0, tapconst = 0;
+  // FASTLD im2col mapping: a thread's B_LD float4 sit in ONE pixel row (row = tid / 16, columns (tid % 16 + 16 i) * 4), so the
+  // (n, oh, ow) state of the row and its two wrap corrections are kept once per thread and only the tap part is per load.
+  unsigned a_off[A_LD], b_roff = 0;
+  int b_ih = 0, b_iw = 0;                       // oh*stride - pad, ow*stride - pad of the thread's pixel row
+  int f_kh[B_LD], f_kw[B_LD], f_tapc[B_LD];     // tap of load i and its byte offset (incl. channel) relative to (b_ih, b_iw)
+  bool f_kval[B_LD];
+  int ih_lim = 0, iw_lim = 0;
   unsigned a_step = 0, c_step = 0, c_wrapw = 0, c_wraph = 0;
   int dw_step = 0, dh_step = 0;
   __amdgpu_buffer_rsrc_t rs_dy, rs_x, rs_dy2;
   unsigned dy_last = 0, x_last = 0;            // last in-range 16-byte offset of each descriptor
   f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;            // DYT 2 parameters (A, nK2, C2) of this thread's 4 output channels
-  f32x4 xs = q0, xb = q0;                                       // XT 1 parameters (scale, shift2) of this thread's 4 input channels
+  f32x4 xs[B_LD], xb[B_LD];                                     // XT 1 parameters (scale, shift2) of this thread's input channels
   bool a_ok[A_LD], b_ok[B_LD];
   f32x4 a2_st[DYT == 2 ? A_LD : 1];
   if constexpr (FASTLD) {
-    const long p_lo = t_begin * BKT;
-    long p_hi = t_end * BKT; if (p_hi > g.P) p_hi = g.P;
+    const long p_lo = (long)t_begin * BKT;
+    long p_hi = (long)t_end * BKT; if (p_hi > g.P) p_hi = g.P;
     long rows = p_hi - p_lo; if (rows < 1) rows = 1;
     const unsigned ld4y = (unsigned)(g.ld_dy * 4), ld4x = (unsigned)(g.ld_x * 4);
     const unsigned dy_bytes = (unsigned)((rows - 1) * ld4y + (unsigned)g.Co * 4u);
@@ -1082,12 +1086,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
         q0 = *reinterpret_cast<const f32x4*>(F.bcoef + co);
         q1 = *reinterpret_cast<const f32x4*>(F.bcoef + g.Co + co);
         q2 = *reinterpret_cast<const f32x4*>(F.bcoef + 2 * g.Co + co);
-      }
-    }
-    if constexpr (XT == 1) {
-      if (kvalid) {
-        xs = *reinterpret_cast<const f32x4*>(F.xcoef + 2 * g.SC + kc);
-        xb = *reinterpret_cast<const f32x4*>(F.xcoef + 4 * g.SC + kc);
       }
     }
     const long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
@@ -1105,16 +1103,39 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     c_wrapw = (unsigned)(g.stride * g.SW - g.OW * g.stride) * ld4x;
     c_wraph = (unsigned)(g.SH * g.SW - g.OH * g.stride * g.SW) * ld4x;
     dw_step = b16 * g.stride; dh_step = a16 * g.stride;
-    ih_lim = g.OH * g.stride + kkh - g.pad;
-    iw_lim = g.OW * g.stride + kkw - g.pad;
-    tapconst = ((kkh - g.pad) * g.SW + (kkw - g.pad)) * (int)ld4x + kc * 4;
+    ih_lim = g.OH * g.stride - g.pad;
+    iw_lim = g.OW * g.stride - g.pad;
+    {
+      const long p = p_lo + (tid >> 4);
+      const long n = p / ohw;
+      const int rem = (int)(p - n * ohw);
+      const int oh = rem / g.OW, ow = rem - oh * g.OW;
+      b_ih = oh * g.stride - g.pad;
+      b_iw = ow * g.stride - g.pad;
+      b_roff = (unsigned)((((int)(n - n_lo) * g.SH + oh * g.stride) * g.SW + ow * g.stride) * (long)ld4x);
+    }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      b_ih[i] = boh[i] * g.stride + kkh - g.pad;
-      b_iw[i] = bow[i] * g.stride + kkw - g.pad;
-      b_roff[i] = (unsigned)(((bn_[i] - (int)n_lo) * g.SH + boh[i] * g.stride) * g.SW + bow[i] * g.stride) * ld4x;
+      const int kcol_i = n0 + ((tid & 15) + 16 * i) * 4;
+      f_kval[i] = kcol_i < g.Ktot;
+      int tap = 0, kc_i = 0;
+      if (f_kval[i]) { tap = kcol_i / g.SC; kc_i = kcol_i - tap * g.SC; }
+      f_kh[i] = tap / g.KW; f_kw[i] = tap - f_kh[i] * g.KW;
+      f_tapc[i] = ((f_kh[i] - g.pad) * g.SW + (f_kw[i] - g.pad)) * (int)ld4x + kc_i * 4;
+      if constexpr (XT == 1) {
+        xs[i] = xb[i] = q0;
+        if (f_kval[i]) {
+          xs[i] = *reinterpret_cast<const f32x4*>(F.xcoef + 2 * g.SC + kc_i);
+          xb[i] = *reinterpret_cast<const f32x4*>(F.xcoef + 4 * g.SC + kc_i);
+        }
+      }
     }
   }
+  // the wrap constants live in vector registers (pinned: as scalars each select re-copies its constant every tile)
+  int v_ows = g.OW * g.stride, v_ohs = g.OH * g.stride, v_str = g.stride;
+  unsigned v_wrapw = c_wrapw, v_wraph = c_wraph;
+  if constexpr (FASTLD && !(OCC >= 4 && DYT != 0))      // (the 4-per-CU fused variant has no registers to spare)
+    asm volatile("" : "+v"(v_ows), "+v"(v_ohs), "+v"(v_str), "+v"(v_wrapw), "+v"(v_wraph));
   auto load_tile_fast = [&]() {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
@@ -1127,16 +1148,16 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      const bool ok = kvalid && (unsigned)b_ih[i] < (unsigned)g.SH && (unsigned)b_iw[i] < (unsigned)g.SW;
-      const unsigned off = ok ? b_roff[i] + (unsigned)tapconst : OOB;
+      const bool ok = f_kval[i] && (unsigned)(b_ih + f_kh[i]) < (unsigned)g.SH && (unsigned)(b_iw + f_kw[i]) < (unsigned)g.SW;
+      const unsigned off = ok ? b_roff + (unsigned)f_tapc[i] : OOB;
       b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
       if constexpr (XT == 1 && MASKX) b_ok[i] = off <= x_last;
-      b_iw[i] += dw_step; b_ih[i] += dh_step; b_roff[i] += c_step;
-      const bool w = b_iw[i] >= iw_lim;
-      b_iw[i] -= w ? g.OW * g.stride : 0; b_ih[i] += w ? g.stride : 0; b_roff[i] += w ? c_wrapw : 0u;
-      const bool h = b_ih[i] >= ih_lim;
-      b_ih[i] -= h ? g.OH * g.stride : 0; b_roff[i] += h ? c_wraph : 0u;
     }
+    b_iw += dw_step; b_ih += dh_step; b_roff += c_step;
+    const bool w = b_iw >= iw_lim;
+    b_iw -= w ? v_ows : 0; b_ih += w ? v_str : 0; b_roff += w ? v_wrapw : 0u;
+    const bool h = b_ih >= ih_lim;
+    b_ih -= h ? v_ohs : 0; b_roff += h ? v_wraph : 0u;
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_tile_vec = [&]() {   // loads the tile the running state points at, then advances the state by one tile
@@ -1160,9 +1181,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
       while (bow[i] >= g.OW) { bow[i] -= g.OW; if (++boh[i] == g.OH) { boh[i] = 0; ++bn_[i]; } }
     }
   };
-  auto load_tile = [&](long t) {
+  auto load_tile = [&](int t) {
     if (VEC) { load_tile_vec(); return; }
-    const long p0 = t * BKT;
+    const long p0 = (long)t * BKT;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int row = (tid + 256 * i) / AC4;
@@ -1212,8 +1233,12 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      const int row = (tid + 256 * i) / BC4;
-      *reinterpret_cast<f32x4*>(b + row * LDB + bc4 * 4) = b_st[i];
+      if constexpr (FASTLD) {
+        *reinterpret_cast<f32x4*>(b + (tid >> 4) * LDB + ((tid & 15) + 16 * i) * 4) = b_st[i];
+      } else {
+        const int row = (tid + 256 * i) / BC4;
+        *reinterpret_cast<f32x4*>(b + row * LDB + bc4 * 4) = b_st[i];
+      }
     }
   };
   // Operand transforms on the staged registers, one element at a time: in the K loop they are issued behind the MFMAs of the
@@ -1229,7 +1254,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     } else if (el < EL) {
       if constexpr (XT == 1) {
         const int i = el - EL_A;
-        const f32x4 v = edrl_bn_relu2(b_st[i], xs, xb);
+        const f32x4 v = edrl_bn_relu2(b_st[i], xs[i], xb[i]);
         if constexpr (MASKX) b_st[i] = b_ok[i] ? v : zero4w; else b_st[i] = v;
       }
     }
@@ -1250,29 +1275,35 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     for (int el = 0; el < EL; ++el) transform_piece(el);
     store_tile(0);
     __syncthreads();
-    for (long t = t_begin; t < t_end; ++t) {
-      const int buf = (int)((t - t_begin) & 1);
+    for (int t = t_begin; t < t_end; ++t) {
+      const int buf = (t - t_begin) & 1;
       if (t + 1 < t_end) load_tile(t + 1);
       const float* a = As + buf * BKT * LDA + wm0 + li;
       const float* b = Bs + buf * BKT * LDB + wn0 + li;
       // software pipeline over the k-steps: the fragments of step s+1 are requested BEFORE the TM*TN MFMAs of step s
       // are issued (pinned with scheduling-group barriers: left alone the compiler issues them after, and the wave
       // then waits out the LDS latency with an idle MFMA pipe at every step)
+      // (volatile: each fragment stays ONE ds_read_b32 with an immediate offset.  Left to merge them, the compiler forms
+      // ds_read2 pairs whose 8-bit offsets need a fresh base register per k-step -- 16 VALU adds per tile, and next to the fp32
+      // MFMA a VALU instruction is matrix-pipe time while an LDS instruction is not.)
+      typedef const volatile __attribute__((address_space(3))) float* lds_vptr;
+      const lds_vptr av = (lds_vptr)a;
+      const lds_vptr bv = (lds_vptr)b;
       float af[2][TM], bf[2][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[0][i] = a[lh * LDA + i * 32];
+      for (int i = 0; i < TM; ++i) af[0][i] = av[lh * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[0][j] = b[lh * LDB + j * 32];
-      __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);     // step-0 fragments
+      for (int j = 0; j < TN; ++j) bf[0][j] = bv[lh * LDB + j * 32];
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);     // step-0 fragments
 #pragma unroll
       for (int sidx = 0; sidx < BKT / 2; ++sidx) {
         const int cur = sidx & 1, nxt = cur ^ 1;
         if (sidx + 1 < BKT / 2) {
           const int k = 2 * (sidx + 1) + lh;
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[nxt][i] = a[k * LDA + i * 32];
+          for (int i = 0; i < TM; ++i) af[nxt][i] = av[k * LDA + i * 32];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bf[nxt][j] = b[k * LDB + j * 32];
+          for (int j = 0; j < TN; ++j) bf[nxt][j] = bv[k * LDB + j * 32];
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1283,7 +1314,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
         // (its VALU instructions are scheduled as one more group of the step's pipeline)
         const bool xf = EL > 0 && sidx >= BKT / 2 - EL;
         if (xf) transform_piece(sidx - (BKT / 2 - EL));   // (unconditional: on the last tile it re-transforms stale registers that are never stored; a branch here would split the MFMA chain's scheduling region)
-        if (sidx + 1 < BKT / 2) __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);   // DS reads (read2 pairs)
+        if (sidx + 1 < BKT / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS reads
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                             // MFMAs
         if (xf) __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);                                          // transform VALU
       }
@@ -1518,6 +1549,7 @@ static int wgrad_impl(const float* dy, const float* x, float* dw, float* workspa
     return EDRL_EINVAL;
   WgradGeom g;
   g.P = (long)N * Ho * Wo;
+  if (g.P > 0x7fffffffL) return EDRL_EINVAL;      // (the kernels count pixel tiles in 32 bits)
   g.OH = Ho; g.OW = Wo; g.Co = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
   g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
   g.ld_dy = ld_dy; g.ld_x = ld_x;
