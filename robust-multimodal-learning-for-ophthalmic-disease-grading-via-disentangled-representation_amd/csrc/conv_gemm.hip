@@ -20,6 +20,7 @@
 // Global->LDS is register staged and double buffered (one barrier per K tile):
 // tile t+1's loads are issued before tile t's MFMAs and written after them.
 #include "edrl_common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -619,91 +620,119 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const bool lean_flags = EPI == 0 ? !accum
                           : EPI == 1 ? (!accum && !F.ep_mask && (g.flags & GF_EPI_RELU))
                                      : (accum && F.ep_mask != nullptr);
-    const bool lean = m0 + BM <= g.M && !bias && !mul && !relu && lean_flags && !(DGRAD && g.step > 1);
+    const bool lean = m0 + BM <= g.M && !bias && !mul && !relu && lean_flags &&
+                      (!(DGRAD && g.step > 1) || (g.flags & GF_LEAN_STRIDED));
     if (lean) {
       constexpr unsigned OOBE = 0x80000000u;
       constexpr int NT = 32 / RPP2;                         // row groups per 32-row pass
-      const int wv = __builtin_amdgcn_readfirstlane(wave);
-      const long row0 = m0 + (long)(wv >> 1) * WM;
-      const int col0 = n0 + (wv & 1) * WN;
       const bool colok = n < g.NC;
-      const __amdgpu_buffer_rsrc_t rs_d =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(dst + row0 * g.ld_dst + col0), 0, (int)(WM * g.ld_dst * 4), 0x00020000);
-      const u32x4 ws_d = edrl_rsrc_words(dst + row0 * g.ld_dst + col0, (unsigned)(WM * g.ld_dst * 4));   // same descriptor, for the asm store
-      const unsigned vd = colok ? (unsigned)((srow * (int)g.ld_dst + sc4 * 4) * 4) : OOBE;
-      const int rstep_d = RPP2 * (int)g.ld_dst * 4;          // bytes per row group
-      __amdgpu_buffer_rsrc_t rs_x, rs_k;
-      unsigned vx = 0, vk = 0;
-      int rstep_x = 0, rstep_k = 0;
-      f32x4 xr[EPI != 0 ? NT : 1], old[EPI == 2 ? NT : 1];
-      int kb[EPI == 2 ? NT : 1];
-      if constexpr (EPI != 0) {
-        rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)F.ep_x + row0 * F.ld_ep + col0), 0, (int)(WM * F.ld_ep * 4),
-                                                 0x00020000);
-        vx = colok ? (unsigned)((srow * (int)F.ld_ep + sc4 * 4) * 4) : OOBE;
-        rstep_x = RPP2 * (int)F.ld_ep * 4;
-      }
-      if constexpr (EPI == 2) {
-        const int nq = g.NC >> 2;
-        rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)(F.ep_mask + row0 * nq + (col0 >> 2)), 0, WM * nq, 0x00020000);
-        vk = colok ? (unsigned)(srow * nq + sc4) : OOBE;
-        rstep_k = RPP2 * nq;
-      }
+      const int nq = g.NC >> 2;
+      // STRIDED (parity class of a strided data gradient): the rows of the tile are scattered destination pixels, so the lane
+      // offset of each row group is decoded (magic division) relative to a per-workgroup descriptor based at the first image
+      // the tile touches, and the scalar offset is 0.  Otherwise: per-wave descriptor at the wave's first row, fixed lane
+      // offset, the row advance in the scalar offset.
+      auto run = [&](auto STR) {
+        constexpr bool S = decltype(STR)::value;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int wrow0 = (wv >> 1) * WM;
+        long pix0; int colb; unsigned span;                  // descriptor base (destination pixel, column) and its rows
+        if constexpr (S) {
+          const int nf = (int)(((unsigned long long)(unsigned)m0 * g.mg_ohw) >> g.sh_ohw);
+          const int nl = (int)(((unsigned long long)(unsigned)(m0 + BM - 1) * g.mg_ohw) >> g.sh_ohw);
+          pix0 = (long)nf * g.OH * g.OW; colb = 0; span = (unsigned)(nl - nf + 1) * (unsigned)(g.OH * g.OW);
+        } else { pix0 = m0 + wrow0; colb = n0 + (wv & 1) * WN; span = WM; }
+        const u32x4 ws_d = edrl_rsrc_words(dst + pix0 * g.ld_dst + colb, span * (unsigned)g.ld_dst * 4u);
+        const __amdgpu_buffer_rsrc_t rs_d =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dst + pix0 * g.ld_dst + colb), 0, (int)(span * (unsigned)g.ld_dst * 4u), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_x, rs_k;
+        if constexpr (EPI != 0)
+          rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)F.ep_x + pix0 * F.ld_ep + colb), 0,
+                                                   (int)(span * (unsigned)F.ld_ep * 4u), 0x00020000);
+        if constexpr (EPI == 2)
+          rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)(F.ep_mask + pix0 * nq + (colb >> 2)), 0, (int)(span * (unsigned)nq), 0x00020000);
+        const int ldd4 = (int)g.ld_dst * 4, ldx4 = (int)F.ld_ep * 4;
+        // lane offsets (non-strided: fixed; strided: column part here, pixel part per row group)
+        const unsigned cd = colok ? (unsigned)((S ? n : sc4 * 4) * 4) : OOBE;
+        const unsigned ck = colok ? (unsigned)(S ? (n >> 2) : sc4) : OOBE;
+        const unsigned vd = cd + (S ? 0u : (unsigned)(srow * ldd4));
+        const unsigned vx = cd + (S ? 0u : (unsigned)(srow * ldx4));
+        const unsigned vk = ck + (S ? 0u : (unsigned)(srow * nq));
+        f32x4 xr[EPI != 0 ? NT : 1], old[EPI == 2 ? NT : 1];
+        int kb[EPI == 2 ? NT : 1];
+        int prel[S ? NT : 1];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if constexpr (EPI != 0) {       // all operand loads of the pass in flight together: one memory latency per pass
+        for (int i = 0; i < TM; ++i) {
+          if constexpr (S) {      // destination pixel of each row group of the pass, relative to pix0
+            const int ohw = g.OHs * g.OWs;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            xr[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vx, (i * NT + t) * rstep_x, 0));
-            if constexpr (EPI == 2) {
-              old[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)vd, (i * NT + t) * rstep_d, 0));
-              kb[t] = __builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)vk, (i * NT + t) * rstep_k, 0);
+            for (int t = 0; t < NT; ++t) {
+              const int m = (int)m0 + wm0 + i * 32 + t * RPP2 + srow;
+              const int nn = (int)(((unsigned long long)(unsigned)m * g.mg_ohw) >> g.sh_ohw);
+              const int rem = m - nn * ohw;
+              const int ii = (int)(((unsigned long long)(unsigned)rem * g.mg_ow) >> g.sh_ow);
+              const int jj = rem - ii * g.OWs;
+              prel[t] = (int)(((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step - pix0);
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+          auto od = [&](int t) { return S ? vd + (unsigned)(prel[S ? t : 0] * ldd4) : vd; };
+          auto ox = [&](int t) { return S ? vx + (unsigned)(prel[S ? t : 0] * ldx4) : vx; };
+          auto ok = [&](int t) { return S ? vk + (unsigned)(prel[S ? t : 0] * nq) : vk; };
+          auto so = [&](int t, int step) { return S ? 0 : (i * NT + t) * step; };
+          if constexpr (EPI != 0) {       // all operand loads of the pass in flight together: one memory latency per pass
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(stage + sc4 * 4);
-        if (EPI == 0 && stats) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (t * RPP2 + srow) * SLD + sc4 * 4);
-            const f32x4 d = v - kshift;
-            st0 += d;
-            st1 = __builtin_elementwise_fma(d, d, st1);
-            edrl_buffer_store_b128_soff(v, ws_d, vd, (i * NT + t) * rstep_d);
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + (t * RPP2 + srow) * SLD + sc4 * 4);
-            if constexpr (EPI == 1) {
-              const f32x4 pre = edrl_bn_pre2(xr[t], e_scale, e_shift2);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = pre[e] > 0.f ? v[e] : 0.f;
-            }
-            if constexpr (EPI == 2) {
-              v += old[t];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {    // bit e of the sign byte -> all-ones / zero (1-bit signed field extract), AND
-                const float ve = v[e];         // (a copy: bit_cast applied to the vector element itself reads element 0)
-                v[e] = __int_as_float(__float_as_int(ve) & ((kb[t] << (31 - e)) >> 31));
+            for (int t = 0; t < NT; ++t) {
+              xr[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox(t), so(t, RPP2 * ldx4), 0));
+              if constexpr (EPI == 2) {
+                old[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)od(t), so(t, RPP2 * ldd4), 0));
+                kb[t] = __builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)ok(t), so(t, RPP2 * nq), 0);
               }
             }
-            if constexpr (EPI != 0) {
-              st0 += v;
-              st1 = __builtin_elementwise_fma(v, xr[t], st1);
-            }
-            edrl_buffer_store_b128_soff(v, ws_d, vd, (i * NT + t) * rstep_d);
+            __builtin_amdgcn_sched_barrier(0);
           }
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(stage + sc4 * 4);
+          if (EPI == 0 && stats) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (t * RPP2 + srow) * SLD + sc4 * 4);
+              const f32x4 d = v - kshift;
+              st0 += d;
+              st1 = __builtin_elementwise_fma(d, d, st1);
+              edrl_buffer_store_b128_soff(v, ws_d, od(t), so(t, RPP2 * ldd4));
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              f32x4 v = *reinterpret_cast<const f32x4*>(stage + (t * RPP2 + srow) * SLD + sc4 * 4);
+              if constexpr (EPI == 1) {
+                const f32x4 pre = edrl_bn_pre2(xr[t], e_scale, e_shift2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pre[e] > 0.f ? v[e] : 0.f;
+              }
+              if constexpr (EPI == 2) {
+                v += old[t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {    // bit e of the sign byte -> all-ones / zero (1-bit signed field extract), AND
+                  const float ve = v[e];         // (a copy: bit_cast applied to the vector element itself reads element 0)
+                  v[e] = __int_as_float(__float_as_int(ve) & ((kb[t] << (31 - e)) >> 31));
+                }
+              }
+              if constexpr (EPI != 0) {
+                st0 += v;
+                st1 = __builtin_elementwise_fma(v, xr[t], st1);
+              }
+              edrl_buffer_store_b128_soff(v, ws_d, od(t), so(t, RPP2 * ldd4));
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
+      };
+      if (DGRAD && g.step > 1) run(std::true_type{}); else run(std::false_type{});
     } else
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -870,6 +899,12 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   GatherGeom gm = g;
   gather_geom_magic(&gm);
+  {   // strided parity class: the lean epilogue addresses the destination (and the EPI operands) through a descriptor based
+      // at the first image a tile touches
+    const long ohw = (long)g.OHs * g.OWs;
+    const long ldmax = (fuse && fuse->ld_ep > g.ld_dst) ? fuse->ld_ep : g.ld_dst;
+    if (DGRAD && g.step > 1 && ohw > 0 && (BM / ohw + 2) * g.OH * g.OW * ldmax * 4 < (1L << 31)) gm.flags |= GF_LEAN_STRIDED;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, gm, tiles_n, F);
   EDRL_LAUNCH_CHECK();
   return 0;

@@ -62,3 +62,4 @@ struct GatherFuse {
 #define GF_VEC_EPI 4   // set by the host when the float4 epilogue is legal (alignment, NC % 4 == 0)
 #define GF_STATS 8     // emit BatchNorm chunk partials from the vector epilogue
 #define GF_EPI_RELU 16 // EPI 1 without sign bytes: the BatchNorm whose backward is reduced was followed by a ReLU
+#define GF_LEAN_STRIDED 32  // set by the launcher: the per-workgroup destination footprint of a strided parity class fits a 2 GiB descriptor
