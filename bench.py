@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of edrl_amd.FusedAdam")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra timed region with the two views overlapped")
+    ap.add_argument("--no-recompute-leg", action="store_true", help="skip the extra timed region with args.activation_recompute")
     a = ap.parse_args()
 
     import torch
@@ -147,6 +148,24 @@ def main():
     loss = out["loss"].item()
     model.raise_on_bad_labels()
     assert loss == loss, "NaN loss"
+    peak_primary = torch.cuda.max_memory_allocated()
+    # Extra leg (not `value`): the same steps with args.activation_recompute (block outputs and their ReLU sign bytes rebuilt in
+    # backward by the forward's own kernel, bit-identical gradients) -- the memory/throughput trade the C3 configuration runs with.
+    recompute_leg = None
+    if world == 1 and not recompute and not a.no_recompute_leg:
+        del out
+        for t in model.trunks():
+            t.recompute_out = True
+        torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        step(); torch.cuda.synchronize()
+        k3 = min(a.steps, 4)
+        dt3, _, _ = timed_region(k3, False)
+        recompute_leg = {"switch": "args.activation_recompute=True", "value": round(B * world * k3 / dt3, 3), "unit": "images/s",
+                         "ms_per_step": round(dt3 / k3 * 1e3, 3), "steps": k3,
+                         "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                         "note": "block outputs + sign bytes rebuilt in backward (one elementwise pass per block); identical gradients"}
+        for t in model.trunks():
+            t.recompute_out = False
 
     if rank == 0:
         value = B * world * a.steps / dt
@@ -158,7 +177,7 @@ def main():
                        "fundus": [3, HW, HW], "oct": [1, S, HW, HW], "parallelism": f"dp{world}",
                        "optimizer": ("torch.optim.Adam" if a.torch_adam else "FusedAdam") + "(lr=1e-4, weight_decay=1e-6)"},
             "final_loss": loss,
-            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "peak_mem_GiB": round(peak_primary / 2 ** 30, 2),
         }
         if timer is not None:
             ks = timer.summary()
@@ -209,6 +228,8 @@ def main():
                 pass
         if overlap is not None:
             res["view_overlap"] = overlap
+        if recompute_leg is not None:
+            res["activation_recompute"] = recompute_leg
         if recompute:
             res["config"]["activation_recompute"] = True
         if world > 1:

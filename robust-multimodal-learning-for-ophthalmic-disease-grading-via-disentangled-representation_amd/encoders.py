@@ -387,7 +387,7 @@ class _TrunkFn(torch.autograd.Function):
         p0, saved["stem"] = K.stem_fwd(T, x, p, bnd, cap, cb)
         cur = p0
         prev_fused = False
-        for blk in T.blocks:
+        for bidx, blk in enumerate(T.blocks):
             pre, s = blk["name"], blk["stride"]
             # recompute mode: the input of a block that follows a fused block is that block's output, which backward
             # rebuilds from the raw tensors (see get_x in backward) -- it is not kept
@@ -414,8 +414,11 @@ class _TrunkFn(torch.autograd.Function):
                 Cl = cl.shape[-1]
                 Ml = cl.numel() // Cl
                 out = torch.empty_like(cl)
-                kl = torch.empty((Ml, Cl // 4), device=cl.device, dtype=torch.uint8)
-                ops.call_timed_bytes("bn_apply_res", Ml * Cl * (3 * K.elt + 0.25), K.apply_res_name, P(cl), P(fl),
+                # recompute mode: this block's output is rebuilt in backward (by the same kernel), and so are its sign bytes
+                # -- except for the last block, whose output nobody rebuilds
+                keep_kl = not (T.recompute_out and cap is None and bidx + 1 < len(T.blocks))
+                kl = torch.empty((Ml, Cl // 4), device=cl.device, dtype=torch.uint8) if keep_kl else None
+                ops.call_timed_bytes("bn_apply_res", Ml * Cl * (3 * K.elt + (0.25 if keep_kl else 0.0)), K.apply_res_name, P(cl), P(fl),
                                      P(cd if cd is not None else cur), P(fd), P(out), P(kl), Ml, Cl, 1)   # 2 reads + 1 write + sign bytes
                 rec.update(kl=kl)
                 if cap is not None:
@@ -565,8 +568,11 @@ class _TrunkFn(torch.autograd.Function):
                 res, rfc = (rj["cd"], rj["fd"]) if T.blocks[j]["downsample"] else (get_x(j), None)
                 t = torch.empty_like(cl)
                 Cl = cl.shape[-1]
-                ops.call_timed_bytes("bn_apply_res", cl.numel() * 3 * K.elt, K.apply_res_name, P(cl), P(fl), P(res), P(rfc),
-                                     P(t), None, cl.numel() // Cl, Cl, 1)
+                kl = None
+                if rj.get("kl") is None:          # the forward pass did not keep the sign bytes (recompute mode): rebuilt here
+                    kl = rj["kl"] = torch.empty((cl.numel() // Cl, Cl // 4), device=cl.device, dtype=torch.uint8)
+                ops.call_timed_bytes("bn_apply_res", cl.numel() * (3 * K.elt + (0.25 if kl is not None else 0.0)), K.apply_res_name,
+                                     P(cl), P(fl), P(res), P(rfc), P(t), P(kl), cl.numel() // Cl, Cl, 1)
                 out_cache[j] = t
             return t
 
@@ -578,9 +584,9 @@ class _TrunkFn(torch.autograd.Function):
         for bi in range(len(T.blocks) - 1, -1, -1):
             blk = T.blocks[bi]
             pre, s = blk["name"], blk["stride"]
-            ep_lo, keep_lo = lower_ep(bi)
             rec = saved[pre]
-            xin = get_x(bi)
+            xin = get_x(bi)                      # (recompute mode: rebuilds the block below's output AND its sign bytes)
+            ep_lo, keep_lo = lower_ep(bi)
             out_cache.pop(bi, None)
             if rec.get("fused"):
                 bott = T.kind == "bottleneck"
