@@ -196,6 +196,10 @@ def main():
                     "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"]),
                     "algorithmic_flop_per_byte": round(dom["flops"] / dom["bytes"], 2) if dom.get("bytes") else None,
                     "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
+                    # each call priced by whichever of ITS algorithmic flops (MFMA peak) or bytes (8 TB/s) binds: the fused
+                    # BatchNorm layers of stages 1-2 read two K-wide operand tensors and sit on the HBM side of the ridge
+                    "per_call_bound": {"speed_of_light_ms": round(dom["bound_ms"], 3), "measured_ms": round(dom["ms"], 3),
+                                       "frac": round(dom["bound_ms"] / dom["ms"], 4)},
                     "launch_unit": "kernel launches as rocprofv3 counts them (a stride-2 data-gradient call issues one kernel "
                                    "per non-empty parity class; the HIP events bracket the call); rocprofv3's conv_gather_* rows are these "
                                    "launches plus the head's Linear layers, which run the same kernels (key linear_gather below)",
@@ -211,7 +215,7 @@ def main():
                     e.update(bound="hbm", GBps=round(v["GBps"], 1), frac_of_8TBps=round(v["GBps"] / 8000.0, 4),
                              algorithmic_bytes=v["bytes"])
                 else:
-                    e.update(bound="mfma", tflops=round(v["tflops"], 3))
+                    e.update(bound="mfma", tflops=round(v["tflops"], 3), per_call_bound_frac=round(v["bound_ms"] / v["ms"], 4) if v["ms"] > 0 else None)
                     if v.get("bytes"):
                         e.update(algorithmic_GBps=round(v["GBps"], 1), algorithmic_bytes=v["bytes"])
                 res["kernels"][k] = e

@@ -47,20 +47,25 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
+    PEAK_BW = 8.0e12                                    # HBM3E, MI355X_MICROARCH.md
+    PEAK_F32, PEAK_BF16 = 157.3e12, 2.5e15              # dense MFMA peaks
+
     def add(self, kind, flops, e0, e1, kernels=1, nbytes=0.0):
-        r = self.records.setdefault(kind, [0.0, [], 0, 0.0])
+        r = self.records.setdefault(kind, [0.0, [], 0, 0.0, 0.0])
         r[0] += flops
         r[1].append((e0, e1))
         r[2] += kernels
         r[3] += nbytes
+        # speed-of-light time of THIS call: whichever of its algorithmic flops / bytes binds
+        r[4] += max(flops / (self.PEAK_BF16 if kind.endswith("bf16") else self.PEAK_F32), nbytes / self.PEAK_BW)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, (flops, evs, kernels, nbytes) in self.records.items():
+        for kind, (flops, evs, kernels, nbytes, bound_s) in self.records.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)
             out[kind] = {"launches": kernels, "calls": len(evs), "flops": flops, "ms": ms,
-                         "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+                         "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "bound_ms": bound_s * 1e3}
             if nbytes:
                 out[kind]["bytes"] = nbytes
                 out[kind]["GBps"] = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

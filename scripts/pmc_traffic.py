@@ -1,7 +1,7 @@
 """Reduce two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of bench.py to per-launch HBM bytes of the conv kernels.
 Corrections per MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes
 of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B/lane stores.
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <workload description> [<mfma_busy_dir>]"""
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <workload description> [<mfma_busy_dir> [<inst_mix_dir>]]"""
 import csv, glob, json, sys, collections
 
 def collect(d, counter):
@@ -46,6 +46,22 @@ if len(sys.argv) > 5:   # third pass: SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE
                                         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the busy counter over all 1024 SIMDs
                                         "xcd_clock_GHz": gui / 8 / ns if ns else None,
                                         "mfma_busy_frac": busy / (gui / 8) / 1024})
+if len(sys.argv) > 6:   # fourth pass: instruction mix (SQ_INSTS_VALU counts the MFMAs too) and the VALU/MFMA co-execution counter
+    f = sorted(glob.glob(sys.argv[6] + "/**/*counter_collection.csv", recursive=True))[-1]
+    mix = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        fam = "conv_gather" if "conv_gather" in name else ("conv_wgrad" if "conv_wgrad" in name else None)
+        if fam is not None:
+            mix[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+    for fam, c in mix.items():
+        if fam in out["kernels"] and c.get("SQ_INSTS_MFMA"):
+            m = c["SQ_INSTS_MFMA"]
+            out["kernels"][fam].update({"insts_mfma": m, "valu_per_mfma": (c["SQ_INSTS_VALU"] - m) / m,
+                                        "salu_per_mfma": c.get("SQ_INSTS_SALU", 0.0) / m,
+                                        "valu_mfma_coexec_cycles": c.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
+                                        # 64 cycles per v_mfma_f32_32x32x2_f32 + 4 per other vector instruction, on the same lanes
+                                        "pipe_bound_frac_of_peak": 64.0 / (64.0 + 4.0 * (c["SQ_INSTS_VALU"] - m) / m)})
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k in ("conv_gather", "conv_wgrad"):
     if k in out["kernels"]:
