@@ -37,14 +37,14 @@ def _grads_of(edrl_amd, model, data, y, seed, sync=None):
     return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import torch.distributed as dist
         import edrl_amd
         torch.cuda.set_device(0)
-        edrl_amd.dist.init_process_group("gloo", timeout_s=120)
+        edrl_amd.dist.init_process_group(backend, timeout_s=120)
         dev = torch.device("cuda:0")
         args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
         torch.manual_seed(0)
@@ -101,3 +101,23 @@ def test_dp2_medfusion_step_one_gpu_gloo():
         assert n_live > 150
         assert all(any(k in n + "." for k in (".alpha", ".decoder_logits.", ".mlp_2d.", ".mlp_3d.")) for n in dead), dead
     assert outs[0][6] == outs[1][6], "both ranks must hold identical parameters after the step"
+
+
+def test_dp1_medfusion_step_rccl():
+    """The same step through the REAL backend of the N > 1 run: `nccl` (= RCCL) with a single rank on the one GPU of the box --
+    process-group initialisation (fail-fast settings), the bucket all-reduces issued from the post-accumulate hooks on the
+    communication stream, the stream hand-over in finish().  With world 1 the exchanged gradients must equal the plain ones."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, port, q, "nccl"))
+    p.start()
+    out = q.get(timeout=500)
+    p.join(timeout=60)
+    assert out[1] != "error", out[2]
+    rank, worst, wn, in_bucket, n_live, dead, chk, nb = out
+    print(f"[parity] DP1 over RCCL: {n_live} gradients through {nb} bucket all-reduces, worst |exchanged - plain| rel {worst:.2e} ({wn})")
+    assert worst <= 1e-6, (worst, wn)
+    assert in_bucket and n_live > 150
