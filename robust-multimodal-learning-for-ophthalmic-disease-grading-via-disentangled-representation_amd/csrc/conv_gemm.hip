@@ -253,7 +253,7 @@ __device__ __forceinline__ u32x4 edrl_rsrc_words(const void* base, unsigned byte
   return r;
 }
 __device__ __forceinline__ void edrl_buffer_store_b128_soff(f32x4 v, u32x4 rs, unsigned voff, int soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 4" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 7" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
 // BUF (FAST only; host-checked footprints < 2 GiB): both operands come through buffer descriptors -- the gathered one
