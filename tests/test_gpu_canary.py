@@ -34,6 +34,9 @@ GEOMS = [  # N, H, W, Ci, Co, k, stride, pad
     (8, 8, 8, 128, 256, 3, 2, 1), (8, 8, 8, 128, 256, 1, 2, 0), (8, 4, 4, 256, 512, 3, 2, 1), (8, 2, 2, 512, 512, 3, 1, 1),
     (2, 16, 16, 64, 64, 3, 1, 1), (2, 4, 4, 256, 512, 3, 2, 1), (2, 2, 2, 512, 512, 3, 1, 1), (2, 2, 2, 256, 512, 1, 2, 0),
     (3, 7, 5, 64, 256, 1, 1, 0), (3, 7, 5, 256, 64, 1, 1, 0), (1, 13, 11, 64, 64, 3, 2, 1), (5, 9, 9, 16, 20, 3, 1, 1),
+    # full 128-row tiles (the lean buffer-store epilogue) with a channel count that ends inside a tile: the column guard is an
+    # out-of-range lane offset there, the row advance a scalar offset
+    (8, 16, 16, 64, 208, 1, 1, 0), (8, 16, 16, 208, 64, 3, 1, 1), (8, 16, 16, 80, 208, 3, 2, 1),
 ]
 
 
