@@ -200,6 +200,15 @@ def main():
                     # BatchNorm layers of stages 1-2 read two K-wide operand tensors and sit on the HBM side of the ridge
                     "per_call_bound": {"speed_of_light_ms": round(dom["bound_ms"], 3), "measured_ms": round(dom["ms"], 3),
                                        "frac": round(dom["bound_ms"] / dom["ms"], 4)},
+                    # the same launches split by the resource that binds each call: MFMA-bound calls against the MFMA peak,
+                    # HBM-bound calls (algorithmic bytes / 8 TB/s > flops / peak) in GB/s against the HBM spec
+                    "by_bound": {
+                        "mfma": {"calls": dom["by_bound"]["mfma"]["calls"], "ms": round(dom["by_bound"]["mfma"]["ms"], 3),
+                                 "tflops": round(dom["by_bound"]["mfma"]["tflops"], 3),
+                                 "frac": round(dom["by_bound"]["mfma"]["tflops"] / peak, 4)},
+                        "hbm": {"calls": dom["by_bound"]["hbm"]["calls"], "ms": round(dom["by_bound"]["hbm"]["ms"], 3),
+                                "GBps": round(dom["by_bound"]["hbm"]["GBps"], 1),
+                                "frac_of_8TBps": round(dom["by_bound"]["hbm"]["GBps"] / 8000.0, 4)}} if "by_bound" in dom else None,
                     "launch_unit": "kernel launches as rocprofv3 counts them (a stride-2 data-gradient call issues one kernel "
                                    "per non-empty parity class; the HIP events bracket the call); rocprofv3's conv_gather_* rows are these "
                                    "launches plus the head's Linear layers, which run the same kernels (key linear_gather below)",

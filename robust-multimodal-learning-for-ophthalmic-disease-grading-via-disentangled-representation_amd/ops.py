@@ -53,19 +53,32 @@ class KernelTimer:
     def add(self, kind, flops, e0, e1, kernels=1, nbytes=0.0):
         r = self.records.setdefault(kind, [0.0, [], 0, 0.0, 0.0])
         r[0] += flops
-        r[1].append((e0, e1))
+        # speed-of-light time of THIS call: whichever of its algorithmic flops / bytes binds
+        t_f = flops / (self.PEAK_BF16 if kind.endswith("bf16") else self.PEAK_F32)
+        t_b = nbytes / self.PEAK_BW
+        r[1].append((e0, e1, t_b > t_f, flops, nbytes))
         r[2] += kernels
         r[3] += nbytes
-        # speed-of-light time of THIS call: whichever of its algorithmic flops / bytes binds
-        r[4] += max(flops / (self.PEAK_BF16 if kind.endswith("bf16") else self.PEAK_F32), nbytes / self.PEAK_BW)
+        r[4] += max(t_f, t_b)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for kind, (flops, evs, kernels, nbytes, bound_s) in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b in evs)
+            ms = 0.0
+            split = {False: [0, 0.0, 0.0, 0.0], True: [0, 0.0, 0.0, 0.0]}        # hbm-bound? -> calls, ms, flops, bytes
+            for a, b, hbm, fl, by in evs:
+                t = a.elapsed_time(b)
+                ms += t
+                c = split[hbm]
+                c[0] += 1; c[1] += t; c[2] += fl; c[3] += by
             out[kind] = {"launches": kernels, "calls": len(evs), "flops": flops, "ms": ms,
                          "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "bound_ms": bound_s * 1e3}
+            if flops > 0 and nbytes > 0:     # the family split by which resource binds each call (ridge = peak flops / 8 TB/s)
+                m, h = split[False], split[True]
+                out[kind]["by_bound"] = {
+                    "mfma": {"calls": m[0], "ms": m[1], "tflops": m[2] / (m[1] * 1e-3) / 1e12 if m[1] > 0 else 0.0},
+                    "hbm": {"calls": h[0], "ms": h[1], "GBps": h[3] / (h[1] * 1e-3) / 1e9 if h[1] > 0 else 0.0}}
             if nbytes:
                 out[kind]["bytes"] = nbytes
                 out[kind]["GBps"] = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
