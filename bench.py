@@ -9,7 +9,8 @@ forward(high view) -> MK_MMD -> backward -> (DP gradient all-reduce) -> Adam.ste
 (fusion_train.py:189-224).  Inputs are resident in HBM before the timed region.  Workload at N=1 is
 BASELINE.json configs[1] (C1): per-GPU batch 32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32.
 At N>1 it is configs[3] (C3): the same shapes at per-GPU batch 64 (global 512 at N=8), data parallel, with the residual
-blocks' outputs rebuilt in backward so that the fp32 activations of 2 x 64 x 33 images fit one GPU's 288 GB.
+blocks' outputs rebuilt in backward so that the fp32 activations of 2 x 64 x 33 images fit one GPU's 288 GB.  The default
+N=1 line also times that C3 per-GPU workload on the one GPU (`scale_anchor`), so 1 -> N efficiency has an equal-work anchor.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -58,6 +59,7 @@ def main():
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of edrl_amd.FusedAdam")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra timed region with the two views overlapped")
     ap.add_argument("--no-recompute-leg", action="store_true", help="skip the extra timed region with args.activation_recompute")
+    ap.add_argument("--no-anchor-leg", action="store_true", help="skip the N = 1 timing of the C3 per-GPU workload (scale_anchor)")
     a = ap.parse_args()
 
     import torch
@@ -96,9 +98,10 @@ def main():
     opt = (torch.optim.Adam if a.torch_adam else edrl_amd.FusedAdam)(model.parameters(), lr=1e-4, weight_decay=1e-6)
     sync = edrl_amd.GradSync(model) if world > 1 else None
     data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank, drop_oct_high=(a.config == "C4"))
+    run = {"model": model, "opt": opt, "data": data, "y": y}     # what step() drives (the scale-anchor leg swaps it)
 
     def step():
-        return edrl_amd.train_step(model, opt, data, y, grad_sync=sync)
+        return edrl_amd.train_step(run["model"], run["opt"], run["data"], run["y"], grad_sync=sync)
 
     def timed_region(steps, with_timer):
         timer = None
@@ -147,6 +150,7 @@ def main():
                            "identical losses/gradients/running statistics; per-kernel timing not taken in this leg"}
     loss = out["loss"].item()
     model.raise_on_bad_labels()
+    model.raise_on_nonfinite()            # the fused BatchNorm+ReLU loads map NaN to 0: divergence shows in the running statistics
     assert loss == loss, "NaN loss"
     peak_primary = torch.cuda.max_memory_allocated()
     # Extra leg (not `value`): the same steps with args.activation_recompute (block outputs and their ReLU sign bytes rebuilt in
@@ -166,6 +170,34 @@ def main():
                          "note": "block outputs + sign bytes rebuilt in backward (one elementwise pass per block); identical gradients"}
         for t in model.trunks():
             t.recompute_out = False
+
+    # Scale anchor (not `value`): the N > 1 runs of this script use C3 (per-GPU batch 64, block outputs recomputed in backward);
+    # the N = 1 line is C1 (BASELINE.json's single-GPU config).  So that a 1 -> N efficiency compares EQUAL per-GPU work, the
+    # default N = 1 run also times the C3 per-GPU workload on this one GPU (same as `--gpus 1 --config C3`).
+    anchor = None
+    if world == 1 and a.config == "C1" and not a.batch and not a.no_anchor_leg:
+        import gc
+        Ba = CONFIGS["C3"][0]
+        out = None
+        run.clear(); del model, opt, data, y
+        gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        args3 = types.SimpleNamespace(mode="train", batch_size=Ba, encoder_depth=depth, activation_recompute=True,
+                                      encoder_dtype=enc_dtype, oct_encoder="slices", oct3d_depth=18)
+        torch.manual_seed(0)
+        m3 = edrl_amd.MedFusion(2, 2, None, args3).to(dev).train()
+        o3 = (torch.optim.Adam if a.torch_adam else edrl_amd.FusedAdam)(m3.parameters(), lr=1e-4, weight_decay=1e-6)
+        d3, y3 = edrl_amd.synthetic_batch(Ba, HW, HW, S, device=dev, seed=1234, rank=rank)
+        run.update(model=m3, opt=o3, data=d3, y=y3)
+        step(); torch.cuda.synchronize()
+        k4 = min(a.steps, 3)
+        dt4, _, o4 = timed_region(k4, False)
+        l4 = o4["loss"].item()
+        assert l4 == l4, "NaN loss (scale anchor)"
+        anchor = {"config": CONFIGS["C3"][5], "command": "python bench.py --gpus 1 --config C3", "per_gpu_batch": Ba,
+                  "value": round(Ba * k4 / dt4, 3), "unit": "images/s", "ms_per_step": round(dt4 / k4 * 1e3, 3), "steps": k4,
+                  "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                  "note": "the per-GPU workload of every N > 1 run of this script, timed on one GPU: divide the N-GPU `value` by "
+                          "N x this value for a weak-scaling efficiency on equal per-GPU work"}
 
     if rank == 0:
         value = B * world * a.steps / dt
@@ -245,9 +277,13 @@ def main():
             res["activation_recompute"] = recompute_leg
         if recompute:
             res["config"]["activation_recompute"] = True
+        if anchor is not None:
+            res["scale_anchor"] = anchor
         if world > 1:
-            res["scaling_note"] = ("weak: per-GPU batch fixed at %d for every N > 1; the N = 1 line of this script is C1 (per-GPU batch 32), "
-                                   "BASELINE.json's single-GPU config" % B)
+            res["scaling_note"] = ("weak: per-GPU batch fixed at %d for every N > 1 (%s).  The default N = 1 line of this script is C1 "
+                                   "(per-GPU batch 32, BASELINE.json's single-GPU config) and carries the matching single-GPU anchor as "
+                                   "`scale_anchor` (= `python bench.py --gpus 1 --config %s`): efficiency(N) = value(N) / (N x "
+                                   "scale_anchor.value)" % (B, a.config, a.config))
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(depth, HW, S, dev)
         print(json.dumps(res), flush=True)

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_coef_kernel(const float* 
 }
 
 // out = act((x-mean)*scale + shift + residual)
-// res_coef (optional) [4][C] = {mean, rstd, scale, shift}: the residual operand is itself a RAW conv output (the downsample
+// res_coef (optional) [5][C] = {mean, rstd, scale, shift, shift2}: the residual operand is itself a RAW conv output (the downsample
 // branch) and its BatchNorm is applied here, so the branch's normalised copy is never stored.
 template <typename TR, typename TA>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TR* __restrict__ x, const float* __restrict__ mean,
@@ -1155,7 +1155,7 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* re
   return 0;
 }
 
-// BatchNorm apply whose residual operand may itself be a raw conv output with its own BatchNorm (res_fcoef [4][C] =
+// BatchNorm apply whose residual operand may itself be a raw conv output with its own BatchNorm (res_fcoef [5][C] =
 // {mean, rstd, scale, shift}; NULL: the residual is used as is):  out = act((x-mean)*scale+shift + bn_r(residual)).
 int edrl_bn_apply_res_f32(const float* x, const float* fcoef, const float* residual, const float* res_fcoef, float* out,
                           unsigned char* relu_mask, long M, int C, int relu, hipStream_t st) {
@@ -1180,7 +1180,7 @@ int edrl_bn_bwd_reduce_f32(const float* dout, const unsigned char* relu_mask, co
   return 0;
 }
 
-// Second half: partial sums -> dgamma, dbeta and the coefficients bcoef [4][C] = {A, K1, K2, mean} from which the fused conv
+// Second half: partial sums -> dgamma, dbeta and the coefficients bcoef [4][C] = {A, nK2, C2, mean} from which the fused conv
 // kernels form d_raw = A*g - K1 - K2*(x - mean) in their operand loads.  group_ws: nchunks/64 x 2 x C doubles.
 size_t edrl_bn_bwd_group_ws_bytes(long nchunks, int C) {
   return (size_t)((nchunks + FIN_GROUP - 1) / FIN_GROUP) * 2 * C * sizeof(double);

@@ -431,7 +431,7 @@ static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, 
   static const bool buf_env = []() { const char* e = getenv("EDRL_GATHER_BUF"); return !(e && e[0] == '0'); }();
   const long ohw = (long)g.OHs * g.OWs;
   const bool buf = buf_env && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 2 < (1L << 31) &&
-                   (long)g.NC * g.Kfull * 2 < (1L << 31) && g.M < (1L << 31);
+                   (long)g.NC * g.Kfull * 2 < (1L << 31);   // (rows < 2^31: checked by the extern "C" launchers)
   if (buf) return launch_gather_bf16_impl<BN, DGRAD, true>(src, wm, dst, g, st);
   return launch_gather_bf16_impl<BN, DGRAD, false>(src, wm, dst, g, st);
 }

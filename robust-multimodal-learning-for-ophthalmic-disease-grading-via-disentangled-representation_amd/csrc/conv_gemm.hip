@@ -915,8 +915,7 @@ static bool gather_fused_ok(const float* src, const float* wm, const float* dst,
   const long ohw = (long)g.OHs * g.OWs;
   return (g.SC % 16 == 0) && (g.ld_src % 4 == 0) && (g.Kfull % 4 == 0) && (g.NC % 4 == 0) && (g.ld_dst % 4 == 0) &&
          ((((uintptr_t)src | (uintptr_t)wm | (uintptr_t)dst) & 15) == 0) && ohw > 0 &&
-         (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) && (long)g.NC * g.Kfull * 4 < (1L << 31) &&
-         g.M < (1L << 31);
+         (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) && (long)g.NC * g.Kfull * 4 < (1L << 31);   // (rows < 2^31 is enforced by every extern "C" launcher before GatherGeom.M is formed)
 }
 // workgroups per CU: the forward operand transform fits the 128-VGPR budget of 4 per CU, the data-gradient variants (second
 // operand tensor + epilogue reduction) need the 168 of 3 per CU
@@ -985,7 +984,7 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
       static const bool buf_env = []() { const char* e = getenv("EDRL_GATHER_BUF"); return !(e && e[0] == '0'); }();
       const long ohw = (long)g.OHs * g.OWs;
       const bool buf = buf_env && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) &&
-                       (long)g.NC * g.Kfull * 4 < (1L << 31) && g.M < (1L << 31);
+                       (long)g.NC * g.Kfull * 4 < (1L << 31);   // (rows < 2^31: checked by the extern "C" launchers)
       if (buf && variant != 5) {   // 4 workgroups per CU (123 VGPRs, 4 x 40 KiB = all of the LDS): +2-3 % over 3 per CU (variant 5)
         if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st);
         return launch_gather_v2<128, 128, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st);
@@ -1643,8 +1642,8 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
 
 // Weight gradient with the BatchNorm passes on either side folded into the operand loads (dense NHWC tensors):
 //   dY = A*g - K1 - K2*(yraw - mean)      g = masked gradient of this layer's BatchNorm output, yraw = this layer's raw conv
-//                                          output, bcoef [4][Co] = {A, K1, K2, mean} (edrl_bn_bwd_finalize_partials_f32)
-//   X  = relu((x - mean)*scale + shift)    when x_fcoef [4][Ci] = {mean, rstd, scale, shift} of the PREVIOUS layer's BatchNorm
+//                                          output, bcoef [4][Co] = {A, nK2, C2, mean} (edrl_bn_bwd_finalize_partials_f32)
+//   X  = relu(x*scale + shift2)            when x_fcoef [5][Ci] = {mean, rstd, scale, shift, shift2} of the PREVIOUS layer's BatchNorm
 //                                          is given (x is then that layer's raw conv output); x as is when x_fcoef == NULL
 // Needs the buffer-load fast path (edrl_conv2d_fused_ok_f32): -22 otherwise.
 int edrl_conv2d_nhwc_wgrad_bn_f32(const float* g, const float* yraw, const float* bcoef, const float* x,
@@ -1660,7 +1659,7 @@ int edrl_conv2d_nhwc_wgrad_bn_f32(const float* g, const float* yraw, const float
 
 // ---- fused-BatchNorm forward / data gradient (dense NHWC tensors; conv_geom.h GatherFuse)
 // Forward conv whose INPUT is the raw conv output of the previous layer: a = relu((x - mean)*scale + shift) with
-// in_fcoef [4][Ci] = {mean, rstd, scale, shift} (edrl_bn_finalize_partials_f32) is formed in the operand load, and the
+// in_fcoef [5][Ci] = {mean, rstd, scale, shift, shift2} (edrl_bn_finalize_partials_f32) is formed in the operand load, and the
 // BatchNorm chunk partials of the OUTPUT are emitted like edrl_conv2d_nhwc_fwd_stats_f32.
 int edrl_conv2d_nhwc_fwd_bnin_stats_f32(const float* x, const float* in_fcoef, const float* w, float* y, float* stat_part,
                                         size_t stat_part_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
@@ -1697,10 +1696,10 @@ long edrl_conv_dgrad_bn_chunks(int N, int Hi, int Wi, int stride, int pad) {
 }
 
 // Data gradient with the BatchNorm-backward passes on both sides folded in:
-//   operand   dY = A*g - K1 - K2*(yraw - mean), bcoef [4][Co] = {A, K1, K2, mean}
+//   operand   dY = A*g + nK2*yraw + C2, bcoef [4][Co] = {A, nK2, C2, mean}
 //   epilogue  (ep_raw != NULL) dx is the gradient of relu?(bn(ep_raw)) of the layer below: it is masked with ep_mask (sign
 //             bytes [pixel][Ci/4]) or, when ep_mask == NULL and ep_relu, with the decision recomputed from ep_raw and
-//             ep_fcoef [4][Ci] = {mean, rstd, scale, shift}; the masked gradient is stored and (sum g, sum g*xhat) per
+//             ep_fcoef [5][Ci] = {mean, rstd, scale, shift, shift2}; the masked gradient is stored and (sum g, sum g*xhat) per
 //             128-row tile go to ep_part [edrl_conv_dgrad_bn_chunks][2][Ci].
 //   flags     GF_ACCUM (2): dx += (before masking / reduction).
 int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g_in, const float* yraw, const float* bcoef, const float* wt, float* dx, int N,

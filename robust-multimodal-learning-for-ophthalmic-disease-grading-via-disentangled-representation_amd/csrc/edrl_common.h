@@ -31,6 +31,11 @@ __device__ __forceinline__ float edrl_bn_pre(float x, float mean, float scale, f
 __device__ __forceinline__ f32x4 edrl_bn_pre2(f32x4 x, f32x4 scale, f32x4 shift2) {
   return __builtin_elementwise_fma(x, scale, shift2);
 }
+// NaN semantics: v_max_f32 is IEEE maxNum, so relu(NaN) = 0 here whereas torch.relu propagates the NaN.  A NaN / Inf in a raw conv
+// output makes that channel's batch statistics -- hence scale / shift2 and the running statistics -- non-finite, and the fused
+// paths then feed zeros downstream instead of NaNs.  The divergence is therefore caught where it is still visible: the running
+// statistics (train() / bench.py check them, MedFusion.raise_on_nonfinite), not in the K loop (a propagating form is two more
+// VALU instructions per element next to the fp32 MFMA).
 __device__ __forceinline__ f32x4 edrl_bn_relu2(f32x4 x, f32x4 scale, f32x4 shift2) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   return __builtin_elementwise_max(edrl_bn_pre2(x, scale, shift2), z);

@@ -150,9 +150,16 @@ __global__ __launch_bounds__(256) void topk_margin_select_kernel(const float* __
   __shared__ int si[TOPK_MAX];
   __shared__ float red[4];
   const int b = blockIdx.x >> 1, side = blockIdx.x & 1;
-  const int yb = (int)y[b];
-  const int n = side == 0 ? S : (C - 1) * S;
+  const long long yl = y[b];
   const int tid = threadIdx.x;
+  // A label outside [0, C) (deferred label check, medfusion.check_labels: the KeyError is raised later on the host) must not
+  // index anything: the row contributes mean 0 and selects nothing, `sel` stays as the caller zeroed it.  Block-uniform exit.
+  if (yl < 0 || yl >= C) {
+    if (tid == 0) means[b * 2 + side] = 0.f;
+    return;
+  }
+  const int yb = (int)yl;
+  const int n = side == 0 ? S : (C - 1) * S;
   for (int i = tid; i < NP; i += 256) {
     float v = -INFINITY;
     int gi = 0x7fffffff;

@@ -38,9 +38,14 @@ def init_process_group(backend="nccl", device=None, timeout_s=180):
 
 
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None, params=None):
+    def __init__(self, model, bucket_mb=64, process_group=None, params=None, force_collective=False):
+        """`force_collective`: with a single rank the exchange is the identity and is normally skipped; True issues the
+        all-reduce / wait / scale on the communication stream anyway (needs an initialised process group), so that the
+        RCCL code path of the N > 1 run can be executed and checked on a one-GPU box (tests/test_gpu_dist.py)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force_collective = bool(force_collective) and dist.is_initialized()
+        self.collectives_issued = 0      # all-reduces handed to the backend since construction (diagnostics / tests)
         if params is None:
             params = model.live_parameters() if hasattr(model, "live_parameters") else model.parameters()
         self.params = [p for p in params if p.requires_grad][::-1]
@@ -69,7 +74,8 @@ class GradSync:
                 self.index[p] = bi
                 self.slot[p] = len(views) - 1
                 p.grad = v                                   # autograd accumulates into the bucket in place
-            self.buckets.append({"params": ps, "flat": flat, "views": views, "ready": 0, "launched": False, "handle": None})
+            self.buckets.append({"params": ps, "flat": flat, "views": views, "ready": 0, "launched": False, "handle": None,
+                                 "seen": [False] * len(ps)})
         if self.params and self.params[0].is_cuda:
             self.comm_stream = torch.cuda.Stream()
         for p in self.params:
@@ -83,6 +89,7 @@ class GradSync:
                 b["handle"].wait(); b["handle"] = None
             b["flat"].zero_()
             b["ready"], b["launched"] = 0, False
+            b["seen"] = [False] * len(b["params"])
             for p, v in zip(b["params"], b["views"]):
                 if p.grad is not v:                          # someone ran optimizer.zero_grad(set_to_none=True)
                     p.grad = v
@@ -105,15 +112,24 @@ class GradSync:
             p.grad = v
         if not self._sync:
             return
-        b["ready"] += 1
-        if b["ready"] >= len(b["params"]) and not b["launched"]:
+        # One backward per zero_grad()/finish() outside no_sync(): a second gradient for a parameter of an exchanged
+        # bucket would be added on top of an already averaged buffer and the ranks would diverge silently.
+        if b["launched"]:
+            raise RuntimeError("GradSync: a gradient arrived for a bucket that was already exchanged in this step; run "
+                               "extra backward passes inside no_sync() and call finish() once after the last one")
+        si = self.slot[p]
+        if not b["seen"][si]:
+            b["seen"][si] = True
+            b["ready"] += 1
+        if b["ready"] >= len(b["params"]):
             self._launch(b)
 
     def _launch(self, b):
         b["launched"] = True
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
         inv = 1.0 / self.world
+        self.collectives_issued += 1
         if self.comm_stream is not None:
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(self.comm_stream):
@@ -135,14 +151,16 @@ class GradSync:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         for b in self.buckets:                               # re-arm: the next backward starts a new exchange even if the
             b["ready"], b["launched"] = 0, False             # caller zeroes gradients some other way than zero_grad()
+            b["seen"] = [False] * len(b["params"])
 
     def total_bytes(self):
         return sum(b["flat"].numel() * 4 for b in self.buckets)
 
 
-def broadcast_parameters(model, src=0, group=None):
-    """Identical initial weights on every rank (parameters and buffers)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def broadcast_parameters(model, src=0, group=None, force_collective=False):
+    """Identical initial weights on every rank (parameters and buffers).  `force_collective` issues the broadcasts with a
+    single rank too (the identity; exercises the backend on a one-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src, group=group)

@@ -322,6 +322,16 @@ class MedFusion(nn.Module):
             self._label_flag.zero_()
             raise KeyError("label outside the proxy dictionary {0, 1} (fusion_net.py:101,227)")
 
+    def raise_on_nonfinite(self):
+        """One host sync (epoch boundary): every BatchNorm running statistic must be finite.  The fused BatchNorm+ReLU operand
+        loads turn a NaN into 0 (v_max_f32 is maxNum, csrc/edrl_common.h), so a diverged run could otherwise report a finite
+        loss; a non-finite conv output always reaches its BatchNorm's running mean / variance."""
+        bufs = [b for n, b in self.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
+        if bufs and not bool(torch.isfinite(torch.stack([b.float().sum() for b in bufs])).all()):
+            bad = [n for n, b in self.named_buffers() if (n.endswith("running_mean") or n.endswith("running_var"))
+                   and not bool(torch.isfinite(b).all())]
+            raise FloatingPointError(f"non-finite BatchNorm running statistics (training diverged): {bad[:4]}")
+
     def forward_tokens(self, x, x1, y, noise=None):
         """Everything after the encoders (fusion_net.py:894-952). x [B,N2,1024], x1 [B,N3,768]."""
         noise = noise or {}

@@ -264,7 +264,7 @@ def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False, al
 
 
 # ---- convolutions with the neighbouring BatchNorm passes folded into their operand loads / epilogues (include/edrl_hip.h:
-# fcoef [4][C] = {mean, rstd, scale, shift}, bcoef [4][C] = {A, K1, K2, mean})
+# fcoef [5][C] = {mean, rstd, scale, shift, shift2 = shift - mean*scale}, bcoef [4][C] = {A, nK2, C2, mean}; include/edrl_hip.h)
 def conv_fused_ok(N, Hi, Wi, Ci, Co, KH, stride, pad):
     Ho = (Hi + 2 * pad - KH) // stride + 1
     Wo = (Wi + 2 * pad - KH) // stride + 1

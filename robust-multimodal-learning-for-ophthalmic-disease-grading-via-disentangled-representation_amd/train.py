@@ -170,6 +170,8 @@ def train(epoch, train_loader, model, optimizer, log_every=0):
         n_seen += target.shape[0]
     if hasattr(model, "raise_on_bad_labels"):
         model.raise_on_bad_labels()
+    if hasattr(model, "raise_on_nonfinite"):
+        model.raise_on_nonfinite()
     return {"loss": (loss_sum / max(n_batches, 1)).item(), "acc": correct.item() / max(n_seen, 1)}
 
 

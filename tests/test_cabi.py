@@ -29,6 +29,16 @@ def test_argument_errors_are_reported_without_a_gpu(edrl):
     assert fn["edrl_mk_mmd_fwd_f32"](None, None, 4, 4, 2.0, 5, None, None, None) == -22
     assert fn["edrl_bn_train_stats_f32"](None, 8, 6, 6, None, None, None, None, 0.1, 1e-5, None, None, None, None,
                                          None, 0, None) == -22   # C % 4 != 0
+    # row count N*Ho*Wo beyond 2^31 - 1 (GatherGeom.M is an int): every conv launcher must refuse it BEFORE forming M
+    big = dict(N=70000, H=256, W=256)          # 70000 * 256 * 256 = 4.59e9 rows
+    assert fn["edrl_conv2d_nhwc_fwd_f32"](None, None, None, None, None, big["N"], big["H"], big["W"], 16, big["H"], big["W"], 16,
+                                          1, 1, 1, 0, 16, 16, 16, 0, None) == -22
+    assert fn["edrl_conv2d_nhwc_dgrad_f32"](None, None, None, big["N"], big["H"], big["W"], 16, big["H"], big["W"], 16, 1, 1, 1, 0,
+                                            16, 16, 0, None) == -22
+    assert fn["edrl_conv2d_nhwc_fwd_bf16"](None, None, None, None, 0, big["N"], big["H"], big["W"], 64, big["H"], big["W"], 64,
+                                           1, 1, 1, 0, None) == -22
+    assert fn["edrl_conv2d_nhwc_dgrad_bf16"](None, None, None, big["N"], big["H"], big["W"], 64, big["H"], big["W"], 64, 1, 1, 1, 0,
+                                             0, None) == -22
     ws = fn["edrl_conv2d_nhwc_wgrad_workspace_bytes"](4, 56, 56, 64, 64, 3, 3)
     assert ws > 0 and ws % (64 * 9 * 64 * 4) == 0
     assert fn["edrl_bn_workspace_bytes"](3000, 256) == 3 * 3 * 256 * 4

@@ -1,5 +1,6 @@
 """Two data-parallel ranks driving the REAL MedFusion step, rehearsed on one MI355X: both processes use
-cuda:0 and exchange over gloo (host-staged; RCCL needs one GPU per rank, which the driver's 8-GPU run provides).  Checks the
+cuda:0 and exchange over gloo (host-staged; RCCL needs one GPU per rank, which the driver's 8-GPU run provides); a single-rank
+`nccl` group with forced collectives then runs the RCCL code path itself.  Checks the
 DP contract of §8(e): after GradSync.finish() every gradient equals the MEAN of the two ranks' single-rank gradients, where the
 batch-coupled terms (BatchNorm statistics, bt_loss_cross, MK_MMD, EPRL's expand(batch_size)) are per replica; gradients live
 in the flat buckets; EPRL's eval-only parameters are not exchanged; the optimiser then steps both ranks identically."""
@@ -37,7 +38,7 @@ def _grads_of(edrl_amd, model, data, y, seed, sync=None):
     return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", force=False):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -49,7 +50,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         args = types.SimpleNamespace(mode="train", batch_size=2, encoder_depth=18)
         torch.manual_seed(0)
         model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
-        edrl_amd.broadcast_parameters(model)
+        edrl_amd.broadcast_parameters(model, force_collective=force)
         state0 = {k: v.clone() for k, v in model.state_dict().items()}
         shards = [edrl_amd.synthetic_batch(2, 64, 64, 4, device=dev, seed=1234, rank=r) for r in range(world)]
         single = []
@@ -57,10 +58,19 @@ def _worker(rank, world, port, q, backend="gloo"):
             model.load_state_dict(state0)
             single.append(_grads_of(edrl_amd, model, shards[r][0], shards[r][1], 1000 + r))
         model.load_state_dict(state0)
-        sync = edrl_amd.GradSync(model, bucket_mb=8)
+        sync = edrl_amd.GradSync(model, bucket_mb=8, force_collective=force)
         bucket_ptrs = {n: p.grad.data_ptr() for n, p in model.named_parameters() if p.grad is not None}
         opt = edrl_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-6)
-        got = _grads_of(edrl_amd, model, shards[rank][0], shards[rank][1], 1000 + rank, sync)
+        n_rccl, n_kern = -1, -1
+        if force:                                    # count the device kernels the backend itself launched during the step
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                got = _grads_of(edrl_amd, model, shards[rank][0], shards[rank][1], 1000 + rank, sync)
+            names = [e.name for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")]
+            n_kern = len(names)
+            n_rccl = sum(1 for n in names if "nccl" in n.lower() or "rccl" in n.lower())
+        else:
+            got = _grads_of(edrl_amd, model, shards[rank][0], shards[rank][1], 1000 + rank, sync)
         worst, wn = 0.0, ""
         for n, g in got.items():
             want = sum(s[n] for s in single) / world
@@ -72,7 +82,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         opt.step()
         torch.cuda.synchronize()
         chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().item()
-        q.put((rank, worst, wn, in_bucket, len(got), dead, chk, len(sync.buckets)))
+        q.put((rank, worst, wn, in_bucket, len(got), dead, chk, len(sync.buckets), sync.collectives_issued, n_rccl, n_kern))
         dist.destroy_process_group()
     except Exception as e:                            # surface the failure to the parent instead of a silent timeout
         import traceback
@@ -94,30 +104,40 @@ def test_dp2_medfusion_step_one_gpu_gloo():
     for o in outs:
         assert o[1] != "error", o[2]
     outs.sort(key=lambda o: o[0])
-    for rank, worst, wn, in_bucket, n_live, dead, chk, nb in outs:
+    for rank, worst, wn, in_bucket, n_live, dead, chk, nb, ncoll, _, _ in outs:
         print(f"[parity] DP2 rank {rank}: {n_live} exchanged gradients in {nb} buckets, worst |avg - mean(single)| rel {worst:.2e} ({wn})")
         assert worst <= 1e-5, (rank, worst, wn)
         assert in_bucket, "gradients must be views of the flat buckets"
-        assert n_live > 150
+        assert n_live > 150 and ncoll == nb, (ncoll, nb)
         assert all(any(k in n + "." for k in (".alpha", ".decoder_logits.", ".mlp_2d.", ".mlp_3d.")) for n in dead), dead
     assert outs[0][6] == outs[1][6], "both ranks must hold identical parameters after the step"
 
 
 def test_dp1_medfusion_step_rccl():
-    """The same step through the REAL backend of the N > 1 run: `nccl` (= RCCL) with a single rank on the one GPU of the box --
-    process-group initialisation (fail-fast settings), the bucket all-reduces issued from the post-accumulate hooks on the
-    communication stream, the stream hand-over in finish().  With world 1 the exchanged gradients must equal the plain ones."""
+    """The same step through the REAL backend of the N > 1 run: `nccl` (= RCCL) with a single rank on the one GPU of the box.
+    `GradSync(force_collective=True)` makes the world-1 group run what every rank of the N > 1 run does: one
+    `dist.all_reduce(async_op=True)` per bucket issued from the post-accumulate hooks inside `torch.cuda.stream(comm)`, the
+    `handle.wait()` that orders the 1/world scale behind it on that stream, `finish()`'s `wait_stream`, and one `dist.broadcast`
+    per parameter / buffer (`broadcast_parameters(force_collective=True)`).  With one rank SUM is the identity, so the
+    exchanged gradients must equal the plain ones (1e-6) -- which they only do if the stream hand-over is ordered correctly.
+    Covered: RCCL kernels really run (counted with the profiler when it reports device events) and are ordered against the
+    backward and the optimiser.  NOT covered: data actually crossing xGMI between ranks, or any N > 1 deadlock/ordering across
+    processes -- that needs the driver's multi-GPU run (tests/test_dist_gloo.py covers the multi-rank logic over gloo)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(0, 1, port, q, "nccl"))
+    p = ctx.Process(target=_worker, args=(0, 1, port, q, "nccl", True))
     p.start()
     out = q.get(timeout=500)
     p.join(timeout=60)
     assert out[1] != "error", out[2]
-    rank, worst, wn, in_bucket, n_live, dead, chk, nb = out
-    print(f"[parity] DP1 over RCCL: {n_live} gradients through {nb} bucket all-reduces, worst |exchanged - plain| rel {worst:.2e} ({wn})")
+    rank, worst, wn, in_bucket, n_live, dead, chk, nb, ncoll, n_rccl, n_kern = out
+    print(f"[parity] DP1 over RCCL: {n_live} gradients, {ncoll} all-reduces issued for {nb} buckets, profiler saw {n_rccl} RCCL "
+          f"kernels among {n_kern} device events; worst |exchanged - plain| rel {worst:.2e} ({wn})")
+    assert ncoll == nb and nb >= 2, (ncoll, nb)
+    if n_kern > 0:                                   # the profiler reports device activity on this box
+        assert n_rccl >= nb, (n_rccl, nb)
     assert worst <= 1e-6, (worst, wn)
     assert in_bucket and n_live > 150

@@ -68,21 +68,31 @@ def test_mk_mmd_full_size_properties(edrl, dev):
     assert edrl.MK_MMD(a, b).item() == ab, "deterministic"
 
 
-def test_c1_full_shape_step_finite_and_deterministic(edrl, dev):
-    """One full optimisation step at BASELINE.json configs[1] (C1: B=32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT,
-    fp32; fusion_train.py:189-224) -- the workload bench.py times, where the CPU oracle would take minutes.  Size-independent
-    properties: every loss term and every parameter gradient is finite, the predictions are valid class indices, BatchNorm
-    state advanced as the reference's would (2 encoder passes, DILR.bn 4 updates: quirk Q5), and a second run from the same
-    state and seeds reproduces the loss and the updated parameters BIT FOR BIT (ordered split-K / BN reductions, no atomics)."""
+def _free_gpu():
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+
+
+def _full_shape_step(edrl, dev, tag, B, HW, S, enc_dtype="fp32", recompute=False, drop_oct=False, n_runs=2):
+    """One full optimisation step (fusion_train.py:189-224) at a BASELINE.json shape where the CPU oracle would take minutes.
+    Size-independent properties: every loss term and every parameter gradient is finite, the predictions are valid class
+    indices, BatchNorm state advanced as the reference's would (2 encoder passes, DILR.bn 4 updates: quirk Q5) and stayed
+    finite, and a second run from the same state and seeds reproduces the loss and the updated parameters BIT FOR BIT (ordered
+    split-K / BatchNorm reductions, no atomics).  Returns (loss, gradients, peak GiB)."""
     import copy
     import types
-    args = types.SimpleNamespace(mode="train", batch_size=32, encoder_depth=50)
+    _free_gpu()
+    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=50, encoder_dtype=enc_dtype,
+                                 activation_recompute=recompute)
     torch.manual_seed(0)
     model = edrl.MedFusion(2, 2, None, args).to(dev).train()
     state0 = copy.deepcopy(model.state_dict())
-    data, y = edrl.synthetic_batch(32, 224, 224, 32, device=dev, seed=1234)
+    data, y = edrl.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, drop_oct_high=drop_oct)
     runs = []
-    for _ in range(2):
+    for _ in range(n_runs):
         model.load_state_dict(state0)
         opt = edrl.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-6)
         torch.manual_seed(11)
@@ -92,6 +102,7 @@ def test_c1_full_shape_step_finite_and_deterministic(edrl, dev):
         runs.append((out["loss"].clone(), out["loss_MDD"].clone(), out["predicted"].clone(),
                      {n: p.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
                      {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        del out, opt
     loss, mdd, pred, params, grads = runs[0]
     assert torch.isfinite(loss) and torch.isfinite(mdd) and mdd.item() >= 0
     assert pred.dtype == torch.int64 and int(pred.min()) >= 0 and int(pred.max()) <= 1
@@ -100,9 +111,56 @@ def test_c1_full_shape_step_finite_and_deterministic(edrl, dev):
     assert len(grads) > 300                                        # both ResNet-50 trunks + the live head
     sd = model.state_dict()
     assert int(sd["DILR.bn1.num_batches_tracked"]) == 4 and int(sd["transformer_3DNet.trunk.bn1.num_batches_tracked"]) == 2
-    assert torch.equal(runs[1][0], loss) and torch.equal(runs[1][1], mdd) and torch.equal(runs[1][2], pred)
-    for n in params:
-        assert torch.equal(runs[1][3][n], params[n]), f"parameter {n} not reproduced bit for bit"
+    model.raise_on_nonfinite()                                     # every running mean / variance finite (zero-variance layers too)
+    if n_runs > 1:
+        assert torch.equal(runs[1][0], loss) and torch.equal(runs[1][1], mdd) and torch.equal(runs[1][2], pred)
+        for n in params:
+            assert torch.equal(runs[1][3][n], params[n]), f"parameter {n} not reproduced bit for bit"
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    print(f"[parity] C1 full-shape step: loss {loss.item():.6f}, loss_MDD {mdd.item():.3e}, {len(grads)} finite gradients, "
-          f"second run bit-identical, peak memory {peak:.1f} GiB")
+    print(f"[parity] {tag} full-shape step: loss {loss.item():.6f}, loss_MDD {mdd.item():.3e}, {len(grads)} finite gradients, "
+          f"{'second run bit-identical, ' if n_runs > 1 else ''}peak memory {peak:.1f} GiB")
+    del model, data, y, runs, state0
+    _free_gpu()
+    return loss, grads, peak
+
+
+def test_c1_full_shape_step_finite_and_deterministic(edrl, dev):
+    """BASELINE.json configs[1] (C1: B=32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32) -- the workload bench.py times."""
+    _full_shape_step(edrl, dev, "C1", 32, 224, 32)
+
+
+def test_c2_full_shape_step_finite_and_deterministic(edrl, dev):
+    """BASELINE.json configs[2] (C2: B=64, same shapes, bf16 MFMA encoders with fp32 accumulate / statistics / weights)."""
+    _full_shape_step(edrl, dev, "C2 (bf16)", 64, 224, 32, enc_dtype="bf16")
+
+
+def test_c3_per_gpu_shape_step_fits_and_is_deterministic(edrl, dev):
+    """BASELINE.json configs[3] per-GPU workload (C3: global 512 on 8 GPUs = B=64 per GPU, fp32, block outputs recomputed in
+    backward -- what `bench.py --gpus N` runs on every rank).  Besides the properties above: the step must fit the GPU with
+    headroom (peak <= 200 GiB of 288)."""
+    _, _, peak = _full_shape_step(edrl, dev, "C3 per-GPU (B=64 fp32, recompute)", 64, 224, 32, recompute=True)
+    assert peak <= 200.0, f"C3 per-GPU peak memory {peak:.1f} GiB"
+
+
+def test_c3_recompute_gradients_bit_identical_to_stored_activations(edrl, dev):
+    """args.activation_recompute rebuilds the block outputs and their ReLU sign bytes in backward with the forward's own kernel:
+    at B=64 / ResNet-50 / 32 slices and 112x112 images (where the stored-activation run fits beside it) every gradient and the
+    loss must be BIT-identical with and without it."""
+    l0, g0, p0 = _full_shape_step(edrl, dev, "B=64 112x112 stored", 64, 112, 32, recompute=False, n_runs=1)
+    l1, g1, p1 = _full_shape_step(edrl, dev, "B=64 112x112 recompute", 64, 112, 32, recompute=True, n_runs=1)
+    assert torch.equal(l0, l1)
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), f"gradient {n} differs under activation_recompute"
+    assert p1 < p0, (p0, p1)
+    print(f"[parity] activation_recompute at B=64 112x112: {len(g0)} gradients bit-identical, peak {p0:.1f} -> {p1:.1f} GiB")
+
+
+def test_c4_per_gpu_shape_step_oct_dropped_bf16(edrl, dev):
+    """BASELINE.json configs[4] per-GPU workload (C4: B=4, 512x512 fundus + 128-slice OCT, bf16 encoders, second view with the
+    OCT volume dropped = zeros, the reference's missing-modality simulation at data_harvard.py:333-334).  The all-zero volume
+    drives every BatchNorm of the OCT trunk to zero variance in that pass: rstd = 1/sqrt(eps) must stay finite (checked through
+    the running statistics and the gradients), and the step must be deterministic."""
+    _, _, peak = _full_shape_step(edrl, dev, "C4 per-GPU (B=4 512x512 128 slices, OCT dropped, bf16)", 4, 512, 128,
+                                  enc_dtype="bf16", drop_oct=True)
+    assert peak <= 260.0, f"C4 per-GPU peak memory {peak:.1f} GiB"

@@ -24,6 +24,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4            # every per-layer check (relative to the reference tensor's largest element)
 TOL_PINNED = 3e-4     # whole-network parameter gradients, relative Frobenius norm, decisions pinned (fp32 round-off through
                       # up to 53 train-mode BatchNorm layers: the forward itself is 1e-5 .. 1e-4 from fp64 at these sizes)
+# Measured worst case per CASE (MI355X, round 2, gpurun_out/r2_layerwise3.log; worst tensor's relative Frobenius / worst element;
+# forward rel err in brackets).  Any change of TOL_PINNED must be read against this table -- it was raised 1e-4 -> 3e-4 in round 2
+# after ResNet-50 4x224x224 measured 1.081e-4 on layer4.1.bn3.weight (the forward alone is 1.1e-4 from fp64 there):
+#   ResNet-18  8x99x85   seeds 1/1(affine)/5 : 7.2e-06 / 7.3e-06 / 7.3e-06   (elem 8.6e-06)   [fwd 4.8e-06 .. 6.7e-06]
+#   ResNet-34  3x96x70   seed 1              : 1.9e-05                       (elem 2.6e-05)   [fwd 1.6e-05]
+#   ResNet-50  4x75x91   seed 1              : 9.9e-05                       (elem 1.4e-04)   [fwd 8.8e-05]
+#   ResNet-50  4x224x224 seed 1              : 1.4e-04                       (elem 1.5e-04)   [fwd 1.1e-04]
 
 
 def _nchw(t):
