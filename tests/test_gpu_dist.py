@@ -120,9 +120,12 @@ def test_dp1_medfusion_step_rccl():
     `handle.wait()` that orders the 1/world scale behind it on that stream, `finish()`'s `wait_stream`, and one `dist.broadcast`
     per parameter / buffer (`broadcast_parameters(force_collective=True)`).  With one rank SUM is the identity, so the
     exchanged gradients must equal the plain ones (1e-6) -- which they only do if the stream hand-over is ordered correctly.
-    Covered: RCCL kernels really run (counted with the profiler when it reports device events) and are ordered against the
-    backward and the optimiser.  NOT covered: data actually crossing xGMI between ranks, or any N > 1 deadlock/ordering across
-    processes -- that needs the driver's multi-GPU run (tests/test_dist_gloo.py covers the multi-rank logic over gloo)."""
+    Covered: the c10d/ProcessGroupNCCL path of every bucket (communicator creation, the collective enqueued on RCCL's
+    internal stream, the work object's event hand-over to the communication stream, the scale behind it, `finish()`), ordered
+    against the backward and the optimiser.  NOT covered -- and not coverable on a one-GPU box: RCCL short-cuts a one-rank
+    in-place all-reduce without launching a device kernel (the profiler count printed below is 0 by construction; RCCL refuses
+    two ranks on one GPU), so no reduction kernel runs and no byte crosses xGMI; N > 1 ordering across processes needs the
+    driver's multi-GPU run (tests/test_dist_gloo.py and the 2-rank gloo test above cover the multi-rank logic)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     port = _free_port()
@@ -137,7 +140,5 @@ def test_dp1_medfusion_step_rccl():
     print(f"[parity] DP1 over RCCL: {n_live} gradients, {ncoll} all-reduces issued for {nb} buckets, profiler saw {n_rccl} RCCL "
           f"kernels among {n_kern} device events; worst |exchanged - plain| rel {worst:.2e} ({wn})")
     assert ncoll == nb and nb >= 2, (ncoll, nb)
-    if n_kern > 0:                                   # the profiler reports device activity on this box
-        assert n_rccl >= nb, (n_rccl, nb)
     assert worst <= 1e-6, (worst, wn)
     assert in_bucket and n_live > 150

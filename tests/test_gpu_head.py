@@ -269,7 +269,7 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high, depth, B, HW, S, fi
     check("step.loss_MDD", out["loss_MDD"].cpu().view(1), ref["loss_MDD"].view(1), 10 * tol)
     assert torch.equal(out["predicted"].cpu(), ref["predicted"])
     named = dict(m.named_parameters())
-    worst, nchk = 0.0, 0
+    worst, nchk, worst_fro = 0.0, 0, 0.0
     for n, r in ref["grads"].items():
         key = n
         if ".trunk." in n:      # the trunk registers its tensors with '.' -> '__'
@@ -282,8 +282,22 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high, depth, B, HW, S, fi
         e = ((g - r).abs().max() / sc).item()
         e32 = ((r32["grads"][n].double() - r).abs().max() / sc).item()
         worst = max(worst, e); nchk += 1
+        if fixed:
+            # The HEAD's ReLU decisions are not pinned (only the trunks' are): at 2 x 49 tokens one hidden unit of EPRL.encoder whose
+            # pre-activation is within round-off of zero flips between fp32 and fp64 and moves ONE row of that Linear's gradient
+            # (measured at C0: encoder.3.weight worst element 7.2e-3, Frobenius 8.6e-4, 0.1 % of the elements; selections and
+            # logits unaffected).  So the full-size cases bind the relative Frobenius norm at a fixed 2e-3 and the worst element
+            # at 2e-2 -- or 3 x the fp32-CPU oracle's own distance to fp64 where that is larger (ResNet-50: EPRL_fundus.encoder.0
+            # is 3e-2 from fp64 in the fp32 oracle itself).
+            fro = ((g - r).norm() / r.norm().clamp_min(1e-30)).item()
+            fro32 = ((r32["grads"][n].double() - r).norm() / r.norm().clamp_min(1e-30)).item()
+            worst_fro = max(worst_fro, fro)
+            assert fro < max(2e-3, 3 * fro32), f"grad {n}: relative Frobenius error {fro:.3e} (fp32 oracle {fro32:.3e})"
+            assert e < max(2e-2, 3 * e32), f"grad {n}: worst element {e:.3e} (fp32 oracle {e32:.3e})"
+            continue
         assert e < max(5e-3, min(10 * e32, 2e-2)), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
-    print(f"[parity] full step: {nchk} gradient tensors, worst rel err vs fp64 oracle {worst:.3e}")
+    print(f"[parity] full step: {nchk} gradient tensors, worst rel err vs fp64 oracle {worst:.3e}"
+          + (f", worst relative Frobenius {worst_fro:.3e}" if fixed else ""))
     # Adam moved every parameter that has a gradient
     moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in m.named_parameters() if p.grad is not None)
     assert moved == sum(1 for p in m.parameters() if p.grad is not None)
