@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "conv_geom.h"
+#include "conv_bf16_v3.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -838,6 +839,7 @@ int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat
     g.flags |= GF_STATS;
     g.stat_part = stat_part;
   }
+  if (gather_bf16_v3_ok(g, false)) return launch_gather_bf16_v3(x, w, y, g, false, st);      // K-heavy layers: 256x256 LDS-DMA core
   if (Co <= 64) return launch_gather_bf16<64, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
   return launch_gather_bf16<128, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
 }
@@ -872,8 +874,9 @@ int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N,
       g.Ktot = g.KHs * g.KWs * Co;
       if (g.Ktot == 0 && (flags & GF_ACCUM)) continue;
       g.M = (int)((long)N * g.OHs * g.OWs);
-      const int rc = Ci <= 64 ? launch_gather_bf16<64, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st)
-                              : launch_gather_bf16<128, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st);
+      const int rc = gather_bf16_v3_ok(g, true) ? launch_gather_bf16_v3(dy, wt, dx, g, true, st)
+                     : Ci <= 64 ? launch_gather_bf16<64, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st)
+                                : launch_gather_bf16<128, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st);
       if (rc) return rc;
     }
   return 0;

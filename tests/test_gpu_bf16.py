@@ -57,6 +57,73 @@ def test_conv_bf16_fwd_dgrad(edrl, dev, case):
         assert torch.equal(dwh, ops.conv2d_wgrad_bf16(dyh, x.to(dev), (Co, k, k, Ci), s, p)), "deterministic split-K"
 
 
+V3_CASES = [
+    # N, Ci, H, W, Co, k, s, p : Co (forward) and Ci (data gradient) multiples of 256 where the v3 core must take the call;
+    # ragged row counts (N*Ho*Wo not a multiple of 256, one case below a single tile), padding taps, stride-2 parity classes,
+    # K from 64 (two ring units, shorter than the 3-deep prefetch) to 2304
+    (3, 256, 14, 14, 256, 3, 1, 1),
+    (2, 256, 13, 11, 512, 3, 2, 1),
+    (5, 64, 9, 7, 256, 1, 1, 0),
+    (2, 512, 10, 10, 256, 1, 2, 0),
+    (1, 256, 7, 7, 256, 3, 1, 1),
+    (4, 1024, 6, 5, 256, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", V3_CASES)
+def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
+    """The 256x256 LDS-DMA core (csrc/conv_bf16_v3.hip), forced on (EDRL_BF16_V3=2) at sizes far below its production range:
+    forward (+ fused BatchNorm chunk partials), data gradient (plain, accumulating, stride-2 parity classes) against the fp64
+    convolution of the same bf16 operands at one bf16 ulp of the output range, the chunk partials against sums taken from the
+    kernel's own output rows in fp64 (1e-3 of the per-chunk scale: they come from the unrounded fp32 accumulators), and against
+    the 128-row kernel (EDRL_BF16_V3=0), which must agree to one bf16 ulp (both accumulate k in the same order in fp32; on the
+    production shapes they are bit-identical, scripts/v3_layer_bench.py)."""
+    ops = edrl.ops
+    N, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(N, H, W, Ci, generator=g).bfloat16()
+    w = (torch.randn(Co, k, k, Ci, generator=g) * 0.1).bfloat16()
+    xd = nchw(x.double()).requires_grad_(True)
+    wd = w.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.conv2d(xd, wd, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.double())
+    Ho, Wo = y.shape[2], y.shape[3]
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("EDRL_BF16_V3", mode)
+        yh, part, chunks = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), s, p, stats=True)
+        dxh = dxa = None
+        if Ci % 256 == 0:
+            wt = ops.permute_weight_bf16(w.float().to(dev))
+            dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+            dxh = ops.conv2d_dgrad_bf16(dyh, wt, (N, H, W, Ci), s, p)
+            dxa = ops.conv2d_dgrad_bf16(dyh, wt, (N, H, W, Ci), s, p, out=dxh.clone(), accumulate=True)
+        torch.cuda.synchronize()
+        outs[mode] = (yh.float().cpu(), part.cpu(), dxh.float().cpu() if dxh is not None else None,
+                      dxa.float().cpu() if dxa is not None else None)
+    yv, pv, dv, dav = outs["2"]
+    check(f"v3 conv_fwd{case}", nchw(yv), y, BF16_TOL)
+    check(f"v3 vs v2 conv_fwd{case}", yv, outs["0"][0], BF16_TOL)
+    # chunk partials [chunks][3][Co]: S1 = sum (y - K), S2 = sum (y - K)^2 over the chunk's rows, K = its first row
+    rows = y.detach().permute(0, 2, 3, 1).reshape(-1, Co)
+    M = rows.shape[0]
+    assert pv.shape[0] == (M + 127) // 128
+    for c in range(pv.shape[0]):
+        blk = rows[c * 128:min(M, (c + 1) * 128)]
+        K = pv[c, 2].double()
+        assert float((K - blk[0]).abs().max()) <= BF16_TOL * float(rows.abs().max()), "shift = the chunk's first row (fp32 accumulator)"
+        d = blk - K
+        sc = max(float(d.abs().sum(0).max()), 1e-6)
+        assert float((pv[c, 0].double() - d.sum(0)).abs().max()) <= 1e-3 * sc, f"chunk {c} S1"
+        sc2 = max(float((d * d).sum(0).max()), 1e-6)
+        assert float((pv[c, 1].double() - (d * d).sum(0)).abs().max()) <= 1e-3 * sc2, f"chunk {c} S2"
+    if dv is not None:
+        check(f"v3 conv_dgrad{case}", nchw(dv), xd.grad, BF16_TOL)
+        check(f"v3 conv_dgrad_accum{case}", nchw(dav), 2 * xd.grad, 2 * BF16_TOL)
+        check(f"v3 vs v2 conv_dgrad{case}", dv, outs["0"][2], BF16_TOL)
+
+
 def test_conv_bf16_exact_on_small_integers(edrl, dev):
     """Operand-layout check that cannot hide behind a tolerance: sparse 0/±1 data keeps every sum a small integer,
     exactly representable in bf16, so the result must be bit-exact."""
