@@ -182,6 +182,14 @@ int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* id
                                         size_t part_bytes, int N, int H, int W, int C, hipStream_t stream);
 int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef,
                                        const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t stream);
+/* The same three with the pooled tensor (y) / its gradient (dy) stored as bf16 when the flag is 1: the stem of the bf16 trunk
+ * (C2/C4; the raw stem conv output, the statistics and d_raw stay fp32). */
+int edrl_maxpool3x3s2_bn_fwd_mx(const float* x, const float* fcoef, void* y, int y_bf16, unsigned char* idx, int N, int H, int W,
+                                int C, hipStream_t stream);
+int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
+                                       float* part, size_t part_bytes, int N, int H, int W, int C, hipStream_t stream);
+int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
+                                      const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t stream);
 
 /* bf16 counterparts of the fused-BatchNorm entry points (conv_bf16.hip / bn_pool.hip): bf16 tensors, fp32 coefficient arrays
  * fcoef [5][C] / bcoef [4][C] and fp32 partial sums; same contracts as the _f32 versions above.  Ci % 32 == 0, Co % 32 == 0. */

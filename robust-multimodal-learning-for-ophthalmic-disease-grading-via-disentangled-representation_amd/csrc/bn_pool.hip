@@ -389,7 +389,63 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TR* __restrict__ x,
                                                        const float* __restrict__ res_coef = nullptr) {
   const int C4 = C >> 2;
   const long total = M * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  const long gstride = (long)gridDim.x * blockDim.x;
+  // Fast path (every ResNet layer): C/4 a power of two that divides the grid stride -> a thread keeps ONE column group for the
+  // whole loop: coefficients loaded once, row index by shift (no 64-bit division per element), two elements in flight per trip.
+  if ((C4 & (C4 - 1)) == 0 && (gstride & (C4 - 1)) == 0) {
+    const int lg = __builtin_ctz(C4);
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i & (C4 - 1)) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+    const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c);
+    f32x4 rm = {0.f, 0.f, 0.f, 0.f}, rsc = {1.f, 1.f, 1.f, 1.f}, rsf = {0.f, 0.f, 0.f, 0.f};
+    if (residual && res_coef) {
+      rm = *reinterpret_cast<const f32x4*>(res_coef + c);
+      rsc = *reinterpret_cast<const f32x4*>(res_coef + 2 * (long)C + c);
+      rsf = *reinterpret_cast<const f32x4*>(res_coef + 3 * (long)C + c);
+    }
+    auto one = [&](long ii, const f32x4 xv, f32x4 rv) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = edrl_bn_pre(xv[e], mu[e], sc[e], sf[e]);
+      if (residual) {
+        if (res_coef) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rv[e] = edrl_bn_pre(rv[e], rm[e], rsc[e], rsf[e]);
+        }
+        v += rv;
+      }
+      if (relu) {
+        if (mask_out) {
+          int mb = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mb |= (v[e] > 0.f ? 1 : 0) << e;
+          if (C4 >= 4) {      // 4 neighbouring lanes hold 4 consecutive mask bytes (i, total and the grid stride are multiples of 4):
+            const int b1 = __shfl_down(mb, 1, 64), b2 = __shfl_down(mb, 2, 64), b3 = __shfl_down(mb, 3, 64);   // one dword store
+            if ((threadIdx.x & 3) == 0) *reinterpret_cast<unsigned int*>(mask_out + ii) = (unsigned)(mb | (b1 << 8) | (b2 << 16) | (b3 << 24));
+          } else {
+            mask_out[ii] = (unsigned char)mb;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      st4<TA>(out + (ii >> lg) * ld + c, v);
+    };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (; i + gstride < total; i += 2 * gstride) {
+      const long j = i + gstride;
+      const f32x4 x0 = ld4<TR>(x + (i >> lg) * ld + c), x1 = ld4<TR>(x + (j >> lg) * ld + c);
+      const f32x4 r0 = residual ? ld4<TA>(residual + (i >> lg) * ld + c) : z4;
+      const f32x4 r1 = residual ? ld4<TA>(residual + (j >> lg) * ld + c) : z4;
+      one(i, x0, r0);
+      one(j, x1, r1);
+    }
+    if (i < total) one(i, ld4<TR>(x + (i >> lg) * ld + c), residual ? ld4<TA>(residual + (i >> lg) * ld + c) : z4);
+    return;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const long r = i / C4;
     const int c = (int)(i - r * C4) * 4;
     const f32x4 xv = ld4<TR>(x + r * ld + c);
@@ -610,8 +666,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v4_kernel(const T* __res
 // (gather form: an input pixel collects dy of every window whose arg-max tap points at it) and the ReLU decision from the raw
 // tensor: MODE 0 reduces (sum g, sum g*xhat) per 1024-pixel chunk [chunk][3][C] (colstat layout), MODE 1 writes
 // d_raw = A*g + nK2*x + C2.  fcoef [5][C], bcoef [4][C] as in the fused conv kernels.
+template <typename TY>
 __global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ fcoef,
-                                                             float* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
+                                                             TY* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
                                                              int W, int C, int Ho, int Wo) {
   const int C4 = C >> 2;
   const long total = (long)N * Ho * Wo * C4;
@@ -641,30 +698,36 @@ __global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const float* __rest
         any = true;
       }
     }
-    *reinterpret_cast<f32x4*>(y + i * 4) = best;
+    st4<TY>(y + i * 4, best);
     *reinterpret_cast<unsigned int*>(idx + i * 4) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
   }
 }
 
-__device__ __forceinline__ f32x4 maxpool_bn_gather_g(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+// Gradient of the fused stem (BatchNorm + ReLU + 3x3/s2/p1 max-pool) at input pixel (n, h, w), channels c..c+3: the windows that
+// contain the pixel are enumerated directly -- an even h lies in ONE window row (ho = h/2, tap kh = 1), an odd h in two
+// (ho = (h+1)/2 with kh = 0, ho = (h-1)/2 with kh = 2), likewise for w -- so at most 4 (dy, arg-max byte) pairs are read and no
+// tap is tested that cannot match (the scan over all 9 taps with its parity tests was most of this kernel's instruction count).
+template <typename TY>
+__device__ __forceinline__ f32x4 maxpool_bn_gather_g(const TY* __restrict__ dy, const unsigned char* __restrict__ idx,
                                                      const f32x4 xr, const f32x4 sc, const f32x4 sh, int n, int h, int w, int c,
                                                      int C, int Ho, int Wo) {
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const int nh = (h & 1) ? 2 : 1, nw = (w & 1) ? 2 : 1;
+  const int ho0 = (h + 1) >> 1, wo0 = (w + 1) >> 1;          // first candidate: kh = (h&1) ? 0 : 1
+  const int kh0 = (h & 1) ? 0 : 1, kw0 = (w & 1) ? 0 : 1;
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    const int th = h + 1 - kh;
-    if (th < 0 || (th & 1)) continue;
-    const int ho = th >> 1;
+  for (int a = 0; a < 2; ++a) {
+    if (a >= nh) break;
+    const int ho = ho0 - a, kh = kh0 + 2 * a;                  // second candidate (odd h only): ho = (h-1)/2, kh = 2
     if (ho >= Ho) continue;
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int tw = w + 1 - kw;
-      if (tw < 0 || (tw & 1)) continue;
-      const int wo = tw >> 1;
+    for (int b = 0; b < 2; ++b) {
+      if (b >= nw) break;
+      const int wo = wo0 - b, kw = kw0 + 2 * b;
       if (wo >= Wo) continue;
       const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
       const unsigned m = *reinterpret_cast<const unsigned int*>(idx + o);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+      const f32x4 g = ld4<TY>(dy + o);
       const unsigned tap = (unsigned)(kh * 3 + kw);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -677,59 +740,59 @@ __device__ __forceinline__ f32x4 maxpool_bn_gather_g(const float* __restrict__ d
   return s;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+#define MPB_ROWS_PER_BLOCK 512     // MODE 1: pixels per workgroup
+template <int MODE, typename TY>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const TY* __restrict__ dy, const unsigned char* __restrict__ idx,
                                                              const float* __restrict__ x, const float* __restrict__ fcoef,
                                                              const float* __restrict__ bcoef, float* __restrict__ part,
                                                              float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
-  // MODE 0: grid (chunks of BN_ROWS_PER_CHUNK pixels, C/256 column blocks), reduction as colstat_kernel<1>
-  // MODE 1: grid-stride elementwise
+  // Both modes: grid (row chunks, C/256 column blocks); a workgroup walks a CONTIGUOUS pixel range with CG = min(C/4, 64) column
+  // lanes x RL = 256/CG pixel lanes; the (n, h, w) of a lane's pixel is decoded once (the only 64-bit division) and then advanced
+  // by RL pixels per step with carries -- no per-element division.
+  // MODE 0: chunks of BN_ROWS_PER_CHUNK pixels, reduction as colstat_kernel<1>;  MODE 1: MPB_ROWS_PER_BLOCK pixels, d_raw written.
   const int C4 = C >> 2;
   const long M = (long)N * H * W;
-  if (MODE == 1) {
-    const long total = M * C4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-      const long r = i / C4;
-      const int c = (int)(i - r * C4) * 4;
-      const int w = (int)(r % W);
-      const long t = r / W;
-      const int h = (int)(t % H), n = (int)(t / H);
-      const f32x4 xr = *reinterpret_cast<const f32x4*>(x + r * C + c);
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c);
-      const f32x4 g = maxpool_bn_gather_g(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo);
-      const f32x4 A = *reinterpret_cast<const f32x4*>(bcoef + c);
-      const f32x4 nK2 = *reinterpret_cast<const f32x4*>(bcoef + (long)C + c);
-      const f32x4 C2 = *reinterpret_cast<const f32x4*>(bcoef + 2 * (long)C + c);
-      *reinterpret_cast<f32x4*>(dx + r * C + c) = edrl_bn_bwd_dx2(g, xr, A, nK2, C2);
-    }
-    return;
-  }
-  __shared__ float sh_[256 * 8];
   const int CG = C4 < 64 ? C4 : 64;
   const int RL = 256 / CG;
   const int tid = threadIdx.x;
   const int cg = tid % CG, rl = tid / CG;
   const int c = (blockIdx.y * 64 + cg) * 4;
-  const long row0 = (long)blockIdx.x * BN_ROWS_PER_CHUNK;
-  long row1 = row0 + BN_ROWS_PER_CHUNK;
+  const long row0 = (long)blockIdx.x * (MODE == 1 ? MPB_ROWS_PER_BLOCK : BN_ROWS_PER_CHUNK);
+  long row1 = row0 + (MODE == 1 ? MPB_ROWS_PER_BLOCK : BN_ROWS_PER_CHUNK);
   if (row1 > M) row1 = M;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-  if (c < C && rl < RL) {
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(fcoef + c);
-    const f32x4 rs = *reinterpret_cast<const f32x4*>(fcoef + (long)C + c);
+  if (c < C && rl < RL && row0 + rl < row1) {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c);
-    for (long r = row0 + rl; r < row1; r += RL) {
-      const int w = (int)(r % W);
-      const long t = r / W;
-      const int h = (int)(t % H), n = (int)(t / H);
+    f32x4 p0, p1, p2;
+    if (MODE == 1) {
+      p0 = *reinterpret_cast<const f32x4*>(bcoef + c);                 // A
+      p1 = *reinterpret_cast<const f32x4*>(bcoef + (long)C + c);       // nK2
+      p2 = *reinterpret_cast<const f32x4*>(bcoef + 2 * (long)C + c);   // C2
+    } else {
+      p0 = *reinterpret_cast<const f32x4*>(fcoef + c);                 // mean
+      p1 = *reinterpret_cast<const f32x4*>(fcoef + (long)C + c);       // rstd
+      p2 = p0;
+    }
+    long r = row0 + rl;
+    int w = (int)(r % W);
+    const long t = r / W;
+    int h = (int)(t % H), n = (int)(t / H);
+    for (; r < row1; r += RL) {
       const f32x4 xr = *reinterpret_cast<const f32x4*>(x + r * C + c);
-      const f32x4 g = maxpool_bn_gather_g(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo);
-      s0 += g;
-      s1 += g * ((xr - mu) * rs);
+      const f32x4 g = maxpool_bn_gather_g<TY>(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo);
+      if (MODE == 1) {
+        *reinterpret_cast<f32x4*>(dx + r * C + c) = edrl_bn_bwd_dx2(g, xr, p0, p1, p2);
+      } else {
+        s0 += g;
+        s1 += g * ((xr - p0) * p1);
+      }
+      w += RL;
+      while (w >= W) { w -= W; if (++h == H) { h = 0; ++n; } }
     }
   }
+  if (MODE == 1) return;
+  __shared__ float sh_[256 * 8];
   float* my = sh_ + tid * 8;
 #pragma unroll
   for (int e = 0; e < 4; ++e) { my[e] = s0[e]; my[4 + e] = s1[e]; }
@@ -1264,37 +1327,63 @@ int edrl_bn_train_stats_fcoef_f32(const float* x, long M, int C, const float* ga
 }
 // Stem max-pool with the BatchNorm + ReLU of its input folded in (x = RAW stem conv output [N,H,W,C], fcoef [5][C]):
 // y [N,Ho,Wo,C] = maxpool3x3/s2/p1(relu(x*scale + shift2)), idx = arg-max tap bytes.
-int edrl_maxpool3x3s2_bn_fwd_f32(const float* x, const float* fcoef, float* y, unsigned char* idx, int N, int H, int W, int C,
-                                 hipStream_t st) {
+int edrl_maxpool3x3s2_bn_fwd_mx(const float* x, const float* fcoef, void* y, int y_bf16, unsigned char* idx, int N, int H, int W, int C,
+                                hipStream_t st) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bn_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, fcoef, y, idx, N, H,
-                     W, C, Ho, Wo);
+  const dim3 grid(ew_grid((long)N * Ho * Wo * (C / 4)));
+  if (y_bf16)
+    hipLaunchKernelGGL(maxpool_bn_fwd_kernel<__bf16>, grid, dim3(256), 0, st, x, fcoef, (__bf16*)y, idx, N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, grid, dim3(256), 0, st, x, fcoef, (float*)y, idx, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
+}
+int edrl_maxpool3x3s2_bn_fwd_f32(const float* x, const float* fcoef, float* y, unsigned char* idx, int N, int H, int W, int C,
+                                 hipStream_t st) {
+  return edrl_maxpool3x3s2_bn_fwd_mx(x, fcoef, y, 0, idx, N, H, W, C, st);
 }
 // Its backward in two launches (the max-pool gradient and the ReLU decision are rebuilt on the fly in both):
 //   _reduce: partial sums (sum g, sum g*xhat) -> part [ceil(N*H*W/1024)][3][C] (planes = 3 for edrl_bn_bwd_finalize_partials_f32)
 //   _apply : d_raw [N,H,W,C] = A*g + nK2*x + C2 with bcoef [4][C]
-int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef, float* part,
-                                        size_t part_bytes, int N, int H, int W, int C, hipStream_t st) {
+// _mx: the pooled tensor's gradient dy is bf16 (dy_bf16 = 1, the bf16 trunk) or fp32; the raw stem output and d_raw stay fp32.
+int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
+                                       float* part, size_t part_bytes, int N, int H, int W, int C, hipStream_t st) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !part) return EDRL_EINVAL;
   const long M = (long)N * H * W;
   if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bn_bwd_kernel<0>, dim3(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256)), dim3(256), 0, st, dy, idx, x,
-                     fcoef, (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
+  const dim3 grid(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256));
+  if (dy_bf16)
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, x, fcoef,
+                       (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, float>), grid, dim3(256), 0, st, (const float*)dy, idx, x, fcoef,
+                       (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef, float* part,
+                                        size_t part_bytes, int N, int H, int W, int C, hipStream_t st) {
+  return edrl_maxpool3x3s2_bn_bwd_reduce_mx(dy, 0, idx, x, fcoef, part, part_bytes, N, H, W, C, st);
+}
+int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
+                                      const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !bcoef || !d_raw) return EDRL_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const dim3 grid(edrl_cdiv((long)N * H * W, MPB_ROWS_PER_BLOCK), edrl_cdiv(C, 256));
+  if (dy_bf16)
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, x, fcoef, bcoef,
+                       (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, float>), grid, dim3(256), 0, st, (const float*)dy, idx, x, fcoef, bcoef,
+                       (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
 int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef,
                                        const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t st) {
-  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !bcoef || !d_raw) return EDRL_EINVAL;
-  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bn_bwd_kernel<1>, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, st, dy, idx, x, fcoef, bcoef,
-                     (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
-  EDRL_LAUNCH_CHECK();
-  return 0;
+  return edrl_maxpool3x3s2_bn_bwd_apply_mx(dy, 0, idx, x, fcoef, bcoef, d_raw, N, H, W, C, st);
 }
 
 int edrl_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st) {

@@ -290,7 +290,9 @@ class _KBF16:
 
     @staticmethod
     def stem_fwd(T, x, p, bnd, cap, cb):
-        """fp32 stem conv + fp32 statistics, bf16 activation out."""
+        """fp32 stem conv + fp32 statistics, bf16 activation out.  Default (EDRL_FUSE_STEM): BatchNorm + ReLU folded into the
+        max-pool as in the fp32 trunk -- the pool reads the RAW fp32 conv output and writes the bf16 pooled tensor; the activated
+        112^2 tensor, its sign bytes and (in backward) its gradient never exist."""
         if _STEM_S2D:
             raw, x, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
         else:
@@ -299,6 +301,18 @@ class _KBF16:
         C = raw.shape[-1]
         M = raw.numel() // C
         dev = raw.device
+        N, H, W, _ = raw.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        if _FUSE_STEM and cap is None:
+            fc = torch.empty((5, C), device=dev, dtype=torch.float32)
+            ws, nbytes = _bn_ws(M, C, dev)
+            L.call("edrl_bn_train_stats_fcoef_f32", P(raw), M, C, P(bn["weight"]), P(bn["bias"]), P(bn["running_mean"]),
+                   P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(fc), P(ws), nbytes)
+            p0 = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.bfloat16)
+            idx = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.uint8)
+            ops.call_timed_bytes("maxpool_bn_fwd", M * C * 4.0 + p0.numel() * 3.0, "edrl_maxpool3x3s2_bn_fwd_mx", P(raw), P(fc), P(p0), 1,
+                                 P(idx), N, H, W, C)
+            return p0, ("fused", x, folded, raw, fc, idx)
         m0 = torch.empty(C, device=dev, dtype=torch.float32)
         r0 = torch.empty_like(m0); scale = torch.empty_like(m0); shift = torch.empty_like(m0)
         ws, nbytes = _bn_ws(M, C, dev)
@@ -307,8 +321,6 @@ class _KBF16:
         a0 = torch.empty(raw.shape, device=dev, dtype=torch.bfloat16)
         k0 = torch.empty((M, C // 4), device=dev, dtype=torch.uint8)
         L.call("edrl_bn_apply_mx", P(raw), 0, P(m0), P(scale), P(shift), None, P(a0), 1, P(k0), M, C, 1)
-        N, H, W, _ = a0.shape
-        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         p0 = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.bfloat16)
         idx = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.uint8)
         L.call("edrl_maxpool3x3s2_fwd_bf16", P(a0), P(p0), P(idx), N, H, W, C)
@@ -316,6 +328,20 @@ class _KBF16:
 
     @staticmethod
     def stem_bwd(T, stem, p, dcur, grads, cap, bn_bwd, conv_bwd, needs_x):
+        if stem[0] == "fused":
+            _, x, folded, raw, fc, idx = stem
+            N, H, W, C = raw.shape
+            M = N * H * W
+            ws, nbytes = _bn_ws(M, C, raw.device)
+            ops.call_timed_bytes("maxpool_bn_bwd", M * C * 4.0 + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dcur), 1,
+                                 P(idx), P(raw), P(fc), P(ws), nbytes, N, H, W, C)
+            bc, dg, db = _bcoef_from_partials(ws, (M + 1023) // 1024, 3, M, p["bn1.weight"], fc)
+            grads["bn1.weight"], grads["bn1.bias"] = dg, db
+            draw = torch.empty_like(raw)                               # fp32 gradient for the fp32 stem weight gradient
+            ops.call_timed_bytes("maxpool_bn_bwd", M * C * 8.0 + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dcur), 1,
+                                 P(idx), P(raw), P(fc), P(bc), P(draw), N, H, W, C)
+            grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), folded)
+            return None
         x, folded, raw, a0_shape, m0, r0, k0, idx = stem
         N, H, W, C = a0_shape
         da0 = torch.empty(a0_shape, device=dcur.device, dtype=torch.bfloat16)

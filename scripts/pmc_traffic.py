@@ -4,6 +4,15 @@ of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B/lane
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <workload description> [<mfma_busy_dir> [<inst_mix_dir>]]"""
 import csv, glob, json, sys, collections
 
+def family(name):
+    """Kernel family of a dispatch: the bf16 kernels (C2/C4) are kept apart from the fp32 ones, and the 256x256 LDS-DMA core
+    (conv_gather_bf16_v3) apart from the 128-row bf16 kernel."""
+    for key in ("conv_gather_bf16_v3", "conv_gather_bf16", "conv_wgrad_bf16", "conv_gather", "conv_wgrad"):
+        if key in name:
+            return key
+    return None
+
+
 def collect(d, counter):
     f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))[-1]
     acc = collections.defaultdict(lambda: [0, 0.0])
@@ -11,7 +20,7 @@ def collect(d, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        fam = "conv_gather" if "conv_gather" in name else ("conv_wgrad" if "conv_wgrad" in name else name)
+        fam = family(name) or name
         acc[fam][0] += 1
         acc[fam][1] += float(r["Counter_Value"])
     return acc
@@ -32,7 +41,7 @@ if len(sys.argv) > 5:   # third pass: SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE
     fam_acc = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0])
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        fam = "conv_gather" if "conv_gather" in name else ("conv_wgrad" if "conv_wgrad" in name else None)
+        fam = family(name)
         if fam is None:
             continue
         a = fam_acc[fam]
@@ -51,7 +60,7 @@ if len(sys.argv) > 6:   # fourth pass: instruction mix (SQ_INSTS_VALU counts the
     mix = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        fam = "conv_gather" if "conv_gather" in name else ("conv_wgrad" if "conv_wgrad" in name else None)
+        fam = family(name)
         if fam is not None:
             mix[fam][r["Counter_Name"]] += float(r["Counter_Value"])
     for fam, c in mix.items():
@@ -60,9 +69,12 @@ if len(sys.argv) > 6:   # fourth pass: instruction mix (SQ_INSTS_VALU counts the
             out["kernels"][fam].update({"insts_mfma": m, "valu_per_mfma": (c["SQ_INSTS_VALU"] - m) / m,
                                         "salu_per_mfma": c.get("SQ_INSTS_SALU", 0.0) / m,
                                         "valu_mfma_coexec_cycles": c.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
-                                        # 64 cycles per v_mfma_f32_32x32x2_f32 + 4 per other vector instruction, on the same lanes
-                                        "pipe_bound_frac_of_peak": 64.0 / (64.0 + 4.0 * (c["SQ_INSTS_VALU"] - m) / m)})
+                                        "lds_insts_per_mfma": c.get("SQ_INSTS_LDS", 0.0) / m if c.get("SQ_INSTS_LDS") else None,
+                                        "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
+                                        "lds_idx_active_cycles": c.get("SQ_LDS_IDX_ACTIVE"),
+                                        # fp32 kernels only: 64 cycles per v_mfma_f32_32x32x2_f32 + 4 per other vector instruction, on the same lanes
+                                        "pipe_bound_frac_of_peak": (64.0 / (64.0 + 4.0 * (c["SQ_INSTS_VALU"] - m) / m)) if "bf16" not in fam else None})
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k in ("conv_gather", "conv_wgrad"):
+for k in ("conv_gather", "conv_wgrad", "conv_gather_bf16", "conv_gather_bf16_v3", "conv_wgrad_bf16"):
     if k in out["kernels"]:
         print(k, out["kernels"][k])

@@ -124,6 +124,48 @@ def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
         check(f"v3 vs v2 conv_dgrad{case}", dv, outs["0"][2], BF16_TOL)
 
 
+def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
+    """The bf16 trunk's stem (BatchNorm + ReLU folded into the 3x3/s2 max-pool, edrl_maxpool3x3s2_bn_*_mx): the pooled tensor is
+    the fp32 kernel's result rounded to bf16 ONCE (bit-exact), the arg-max bytes are identical, and the two backward kernels fed
+    a bf16 gradient equal the fp32 kernels fed the same values as fp32, bit for bit (same arithmetic behind an exact widening
+    load).  Odd sizes: ragged pooling windows at the right / bottom edge, a row count that is not a multiple of the chunk."""
+    L = edrl._lib
+    P = L.ptr
+    N, H, W, C = 3, 37, 29, 64
+    g = torch.Generator().manual_seed(8)
+    raw = torch.randn(N, H, W, C, generator=g).to(dev)
+    fc = torch.empty(5, C, device=dev)
+    fc[0] = 0.1 * torch.randn(C, generator=g).to(dev); fc[1] = 1.0 + 0.1 * torch.rand(C, generator=g).to(dev)
+    fc[2] = fc[1] * (0.5 + torch.rand(C, generator=g).to(dev)); fc[3] = 0.1 * torch.randn(C, generator=g).to(dev)
+    fc[4] = fc[3] - fc[0] * fc[2]
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y32 = torch.empty(N, Ho, Wo, C, device=dev); i32 = torch.empty(N, Ho, Wo, C, device=dev, dtype=torch.uint8)
+    y16 = torch.empty(N, Ho, Wo, C, device=dev, dtype=torch.bfloat16); i16 = torch.empty_like(i32)
+    L.call("edrl_maxpool3x3s2_bn_fwd_f32", P(raw), P(fc), P(y32), P(i32), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_fwd_mx", P(raw), P(fc), P(y16), 1, P(i16), N, H, W, C)
+    assert torch.equal(y16, y32.bfloat16()) and torch.equal(i16, i32)
+    dy16 = torch.randn(N, Ho, Wo, C, generator=g).bfloat16().to(dev)
+    dy32 = dy16.float()
+    M = N * H * W
+    nb = L.query("edrl_bn_workspace_bytes", M, C)
+    ws32 = torch.zeros(nb // 4, device=dev); ws16 = torch.zeros(nb // 4, device=dev)
+    L.call("edrl_maxpool3x3s2_bn_bwd_reduce_f32", P(dy32), P(i32), P(raw), P(fc), P(ws32), nb, N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dy16), 1, P(i32), P(raw), P(fc), P(ws16), nb, N, H, W, C)
+    chunks = (M + 1023) // 1024
+    assert torch.equal(ws16[:chunks * 3 * C].view(chunks, 3, C)[:, :2], ws32[:chunks * 3 * C].view(chunks, 3, C)[:, :2])
+    bc = torch.empty(4, C, device=dev)
+    bc[0] = 0.5 + torch.rand(C, generator=g).to(dev); bc[1] = 0.01 * torch.randn(C, generator=g).to(dev)
+    bc[2] = 0.01 * torch.randn(C, generator=g).to(dev); bc[3] = fc[0]
+    d32 = torch.empty_like(raw); d16 = torch.empty_like(raw)
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_f32", P(dy32), P(i32), P(raw), P(fc), P(bc), P(d32), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw), P(fc), P(bc), P(d16), N, H, W, C)
+    assert torch.equal(d16, d32)
+    # and the fp32 pair itself against torch: max-pool of relu(x*scale + shift2), gradient routed to the first arg-max
+    act = torch.relu(torch.addcmul(fc[4], raw, fc[2])).permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    ref = F.max_pool2d(act, 3, 2, 1)
+    check("fused stem fwd vs torch", y32.permute(0, 3, 1, 2).cpu(), ref, 1e-6)
+
+
 def test_conv_bf16_exact_on_small_integers(edrl, dev):
     """Operand-layout check that cannot hide behind a tolerance: sparse 0/±1 data keeps every sum a small integer,
     exactly representable in bf16, so the result must be bit-exact."""
