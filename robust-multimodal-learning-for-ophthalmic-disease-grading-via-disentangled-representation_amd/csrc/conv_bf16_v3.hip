@@ -68,11 +68,22 @@ __device__ __forceinline__ int v3_swz(int r) {
   return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
 }
 
-template <bool DGRAD, int DBG = 0, bool STAGGER = false>
+template <bool DGRAD, int DBG = 0, bool STAGGER = false, int PRIO = 2>
 __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf16* __restrict__ src, const __bf16* __restrict__ wm,
                                                                      __bf16* __restrict__ dst, GatherGeom g, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = 8, TN = 4;                 // wave tile 128 pixels x 64 channels of 16x16 MFMA tiles
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};  // DBG 4 only: s_memtime at entry / loop start / loop end / kernel end, s_memrealtime at entry / end
+  auto cstamp = [&](int i) {
+    if constexpr (DBG == 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[i])::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  unsigned long long* F_dbg = DBG == 4 ? (unsigned long long*)g.stat_shift : nullptr;
+  cstamp(0);
+  if constexpr (DBG == 4) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[4])::"memory");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
@@ -156,6 +167,16 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
     v3_dma16(base + 8192, DBG == 1 ? (boff & 0xfff0u) : boff, rs_b, DBG == 1 ? 0 : wj);
   };
 
+  auto issueA1 = [&](int slot, int j) {
+    if constexpr (DBG == 2) return;
+    v3_dma16(lds0 + (unsigned)slot * V3_UNIT + (unsigned)j * 8192u, DBG == 1 ? (aoff[j] & 0xfff0u) : aoff[j], rs_a, 0);
+  };
+  auto issueB1 = [&](int slot, int j) {
+    if constexpr (DBG == 2) return;
+    v3_dma16(lds0 + (unsigned)slot * V3_UNIT + V3_ABYTES + (unsigned)j * 8192u, DBG == 1 ? (boff & 0xfff0u) : boff, rs_b,
+             (DBG == 1 || j == 0) ? 0 : wj);
+  };
+
   // ---- fragment addressing (bytes inside a unit): row fr (+16 i), k chunk fq at slot fq ^ G[fr]
   const int fr = lane & 15, fq = lane >> 4;
   const int a_rd = (wm0 + fr) * 64 + ((fq ^ v3_swz(fr)) << 4);
@@ -180,42 +201,77 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
 #pragma unroll
     for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const bf16x8*>(s + i * 1024);
   };
-  auto mma = [&](auto MH_, bf16x8 (&af)[4], bf16x8 (&bf)[TN]) {
-    constexpr int MH = decltype(MH_)::value;
-    __builtin_amdgcn_s_setprio(1);
+  // 8 MFMAs: pixel tiles 2q, 2q+1 of half MH against the 4 weight tiles
+  auto mma8 = [&](auto MH_, auto Q_, bf16x8 (&af)[4], bf16x8 (&bf)[TN]) {
+    constexpr int MH = decltype(MH_)::value, Q = decltype(Q_)::value;
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 2 * Q; j < 2 * Q + 2; ++j)
 #pragma unroll
       for (int i = 0; i < TN; ++i)
         acc[i][MH * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][MH * 4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
   };
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
-  // one unit: `cur` weights are multiplied, `nxt` receives the next unit's
-  // STAGGER (off by default; MI355X_MICROARCH.md "Two waves per SIMD", item 9): waves w and w+4 share a SIMD; the older half issues
-  // its four DMA pieces BEFORE the first MFMA group, the younger half AFTER it.  Measured on the 3x3 layers: 1044 vs 1089 TFLOP/s
-  // (l3) / 1111 vs 1134 (l4) against the plain order, so both halves issue first; kept as an A/B switch (EDRL_V3_STAGGER=1).
+  unsigned long long seg[5] = {0, 0, 0, 0, 0};      // DBG 3 only: cycles in {reads + first half, wait, barrier, second half, -}
+  auto stamp = [&]() -> unsigned long long {
+    if constexpr (DBG != 3) return 0ull;
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
+  // The vector-memory path of a CU moves ~64 B/clk: the 32 KiB of one unit take >= 512 cycles of it, and a wave whose DMA
+  // instruction finds the queue full stalls in issue -- with all 8 waves issuing their 4 pieces at one program point the last
+  // ones waited ~600 cycles per unit with no MFMA of theirs in the pipe (in-kernel stamps, scripts/dbg/v3_stamps.py).  So the
+  // pieces are spread over the unit, ONE in front of every group of 8 MFMAs (pixel-operand pieces in the first half, weight
+  // pieces -- whose slot is free as soon as the unit's barrier has passed -- in the second half), and with STAGGER the two
+  // waves that share a SIMD (w, w+4) alternate: one issues its piece before its 8 MFMAs, the other after.
   const bool dma_first = STAGGER ? wave < 4 : true;
+  // one unit: `cur` weights are multiplied, `nxt` receives the next unit's
   auto unit = [&](int u, bf16x8 (&bcur)[TN], bf16x8 (&bnxt)[TN]) {
-    const int slot = u & 3;
+    const int slot = u & 3, nslot = (u + 3) & 3;
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t0 = stamp();
     rdA(slot, 1, an);
-    if (dma_first) { issueA((u + 3) & 3); issueB((u + 3) & 3); }
+    if (dma_first) issueA1(nslot, 0);
     __builtin_amdgcn_sched_barrier(0);
-    mma(H0{}, ac, bcur);
+    mma8(H0{}, H0{}, ac, bcur);
     __builtin_amdgcn_sched_barrier(0);
-    if (!dma_first) { issueA((u + 3) & 3); issueB((u + 3) & 3); }
+    if (!dma_first) issueA1(nslot, 0); else issueA1(nslot, 1);
     __builtin_amdgcn_sched_barrier(0);
-    advance();
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    mma8(H0{}, H1{}, ac, bcur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!dma_first) issueA1(nslot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = stamp();
+    // this wave's pieces of unit u+1 have landed: of the later ones, unit u+2 (4) and the pixel pieces of unit u+3 (2) may fly
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    const unsigned long long t2 = stamp();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t3 = stamp();
     rdB((u + 1) & 3, bnxt);
     rdA((u + 1) & 3, 0, ac);
-    mma(H1{}, an, bcur);
+    if (dma_first) issueB1(nslot, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(H1{}, H0{}, an, bcur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!dma_first) issueB1(nslot, 0); else issueB1(nslot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(H1{}, H1{}, an, bcur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!dma_first) issueB1(nslot, 1);
+    advance();
+    const unsigned long long t4 = stamp();
+    if constexpr (DBG == 3) { seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3; }
   };
 
+  // Static priority for the second-dispatched half (MI355X_MICROARCH.md "Two waves per SIMD", item 4) instead of s_setprio flips
+  // around every MFMA group (PRIO 1): measured +2..5 % on the 3x3 layers (1034 -> 1085, 1110 -> 1133 TFLOP/s), no flips +2..4 %.
+  if constexpr (PRIO == 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
   if (KU > 0) {
     retap();
 #pragma unroll
@@ -225,6 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
     __builtin_amdgcn_sched_barrier(0);
     rdB(0, bc);
     rdA(0, 0, ac);
+    cstamp(1);
     int u = 0;
     for (; u + 1 < KU; u += 2) {
       unit(u, bc, bn);
@@ -233,8 +290,17 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
     if (u < KU) unit(u, bc, bn);
     // the pipeline's tail pieces (zeros into consumed slots) must have landed before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    cstamp(2);
   }
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DBG == 3) {
+    if (lane == 0 && g.stat_part) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(g.stat_part) + ((long)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = seg[i];
+    }
+    return;
+  }
   __syncthreads();
 
   // ---- BatchNorm chunk partials from the fp32 accumulators (forward, GF_STATS): this wave owns one 128-row chunk x 64 channels
@@ -314,6 +380,16 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
       }
     }
   }
+  if constexpr (DBG == 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    cstamp(3);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[5])::"memory");
+    if (lane == 0 && F_dbg) {
+      unsigned long long* o = F_dbg + ((long)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) o[q] = ts[q];
+    }
+  }
 }
 
 bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad) {
@@ -356,10 +432,12 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
   } else {
     const char* de = getenv("EDRL_V3_DBG");
     const int dbg = de ? atoi(de) : 0;
-    if (dbg == 1 || dbg == 2) {
-      auto kd = dbg == 1 ? conv_gather_bf16_v3_kernel<false, 1> : conv_gather_bf16_v3_kernel<false, 2>;
+    if (dbg >= 1 && dbg <= 4) {     // diagnostic builds: 1 cache-resident loads, 2 no DMA, 3 / 4 in-kernel stamps
+      auto kd = dbg == 1 ? conv_gather_bf16_v3_kernel<false, 1> : (dbg == 2 ? conv_gather_bf16_v3_kernel<false, 2> : (dbg == 3 ? conv_gather_bf16_v3_kernel<false, 3> : conv_gather_bf16_v3_kernel<false, 4>));
       (void)hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);
+      GatherGeom gd = g;
+      if (dbg == 4) { gd.stat_shift = (const float*)g.stat_part; gd.flags &= ~GF_STATS; }     // stamps go to the caller's partials buffer
+      hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, gd, tiles_n);
       EDRL_LAUNCH_CHECK();
       return 0;
     }
