@@ -956,9 +956,100 @@ static int launch_gather(const float* src, const float* wm, float* dst, const fl
   return 0;
 }
 
+// ------------------------------------------------------------------ small-M linear (the head's batch-level projections)
+// dst[m][n] = act(sum_k src[m][k] * wm[n][k] + bias[n]) * mul[m][n] (+ dst) for M <= 64 rows (B = 32 / 64 samples: the q-len-1/2
+// attention blocks, PoE / guided projections of fusion_net.py:635-643, 555-566, 929-939): a weight-streaming GEMV-like shape that the
+// 128-row implicit-GEMM tiles run at 1-3 TFLOP/s (16-48 workgroups, each walking all of K serially).  Here one workgroup owns 16
+// output columns; its 4 waves split K four ways, every lane streams 32 contiguous bytes of a weight row per step straight into the
+// fragment of v_mfma_f32_16x16x4_f32 (A = activations, B = weights: element e of the lane's two float4 is the k of MFMA e, the
+// same on both operands, so any fixed assignment of k to lanes is a valid contraction order), and the four partial tiles are
+// summed in wave order through LDS (deterministic).  N/16 workgroups x 4 waves stream the N x K weights exactly once.
+template <int MT>
+__global__ __launch_bounds__(256) void linear_smallm_f32_kernel(const float* __restrict__ src, const float* __restrict__ wm,
+                                                                float* __restrict__ dst, const float* __restrict__ bias,
+                                                                const float* __restrict__ mul, int M, int N, int K, long ld_src,
+                                                                long ld_dst, long ld_aux, int flags) {
+  __shared__ float red[4][MT][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kper = K >> 2, kbeg = wave * kper;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wrow = wm + (long)(n0 + r) * K + 8 * q;
+  const float* arow[MT];
+  bool aok[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) { aok[t] = t * 16 + r < M; arow[t] = src + (long)(aok[t] ? t * 16 + r : 0) * ld_src + 8 * q; }
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int k0 = kbeg; k0 < kbeg + kper; k0 += 32) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(wrow + k0), b1 = *reinterpret_cast<const f32x4*>(wrow + k0 + 4);
+    f32x4 a0[MT], a1[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      a0[t] = aok[t] ? *reinterpret_cast<const f32x4*>(arow[t] + k0) : z4;
+      a1[t] = aok[t] ? *reinterpret_cast<const f32x4*>(arow[t] + k0 + 4) : z4;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t][e], b0[e], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][e], b1[e], acc[t], 0, 0, 0);
+  }
+  // C/D map of the 16x16 tile: col = lane&15 (n), row = 4*(lane>>4) + reg (m)
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][t][e * 64 + lane] = acc[t][e];
+  __syncthreads();
+  const bool relu = flags & GF_RELU, accum = flags & GF_ACCUM;
+  const int e = tid >> 6;                       // thread -> (reg e, lane)
+  const int n = n0 + (lane & 15);
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = t * 16 + 4 * (lane >> 4) + e;
+    if (m < M) {
+      float v = ((red[0][t][tid] + red[1][t][tid]) + red[2][t][tid]) + red[3][t][tid] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      if (mul) v *= mul[(long)m * ld_aux + n];
+      float* p = dst + (long)m * ld_dst + n;
+      if (accum) v += *p;
+      *p = v;
+    }
+  }
+}
+
+// Geometry test + launch; returns -1 when the small-M kernel does not apply
+static int try_linear_smallm(const float* src, const float* wm, float* dst, const float* bias, const float* mul,
+                             const GatherGeom& g, hipStream_t st) {
+  static const bool on = []() { const char* e = getenv("EDRL_LINEAR_SMALLM"); return !(e && e[0] == '0'); }();
+  if (!on || g.KH != 1 || g.KW != 1 || g.pad != 0 || g.step != 1 || g.stride != 1 || g.OHs * g.OWs != 1 || g.SH * g.SW != 1) return -1;
+  if (g.M > 64 || g.M <= 0 || (g.NC % 16) || (g.Ktot % 128) || g.Ktot != g.Kfull || (g.ld_src % 4) || (g.flags & ~(GF_RELU | GF_ACCUM)))
+    return -1;
+  if ((((uintptr_t)src | (uintptr_t)wm) & 15) || g.stat_part) return -1;
+  const int mt = (g.M + 15) / 16;
+  const dim3 grid(g.NC / 16), blk(256);
+  if (mt <= 2)
+    hipLaunchKernelGGL(linear_smallm_f32_kernel<2>, grid, blk, 0, st, src, wm, dst, bias, mul, g.M, g.NC, g.Ktot, g.ld_src, g.ld_dst, g.ld_aux, g.flags);
+  else
+    hipLaunchKernelGGL(linear_smallm_f32_kernel<4>, grid, blk, 0, st, src, wm, dst, bias, mul, g.M, g.NC, g.Ktot, g.ld_src, g.ld_dst, g.ld_aux, g.flags);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 template <bool DGRAD>
 static int dispatch_gather(const float* src, const float* wm, float* dst, const float* bias,
                            const float* mul, const GatherGeom& g, hipStream_t st) {
+  {
+    const int rc = try_linear_smallm(src, wm, dst, bias, mul, g, st);
+    if (rc >= 0) return rc;
+  }
   const bool vec = (g.SC % 4 == 0) && (g.ld_src % 4 == 0) && (g.Kfull % 4 == 0) &&
                    (((uintptr_t)src & 15) == 0) && (((uintptr_t)wm & 15) == 0);
   // 64-wide N tiles for Cout <= 64 and for small grids (the head's Linear layers at 32..1568 rows leave most of the

@@ -103,6 +103,38 @@ def test_linear_epilogues(edrl, dev):
     check("linear_db", bg.grad.cpu(), ba.grad, 2e-5)
 
 
+@pytest.mark.parametrize("rows,cin,cout", [(32, 1024, 1024), (64, 3072, 1024), (7, 1024, 64), (50, 128, 3072), (33, 3072, 16)])
+def test_linear_small_m_kernel(edrl, dev, rows, cin, cout, monkeypatch):
+    """The head's batch-level projections (rows = B or 2B <= 64, fusion_net.py:555-566, 635-643, 929-939) run on the small-M
+    weight-streaming kernel (csrc/conv_gemm.hip linear_smallm_f32_kernel: K split over the 4 waves, ordered LDS reduction).
+    Forward with bias + ReLU + dropout-mask multiply on a strided operand, input and weight gradients, against fp64 at 2e-5;
+    ragged row counts (7, 33, 50); run-to-run deterministic; and equal to the 128-row tile path (EDRL_LINEAR_SMALLM is read once
+    per process, so that comparison is made through the values both must match)."""
+    g = torch.Generator().manual_seed(17)
+    big = torch.randn(rows, 2 * cin, generator=g)
+    x = big[:, cin:]
+    w = torch.randn(cout, cin, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    mask = (torch.rand(rows, cout, generator=g) > 0.2).float() / 0.8
+    ops = edrl.ops
+    bigd = big.to(dev)
+    y = ops.linear_fwd(bigd[:, cin:], w.to(dev), b.to(dev), mask.to(dev), relu=True)
+    ref = F.relu(x.double() @ w.double().t() + b.double()) * mask.double()
+    check(f"small-M linear fwd {rows}x{cin}->{cout}", y.cpu(), ref, 2e-5)
+    assert torch.equal(y, ops.linear_fwd(bigd[:, cin:], w.to(dev), b.to(dev), mask.to(dev), relu=True)), "deterministic"
+    xa = x.clone().requires_grad_(True); wa = w.clone().requires_grad_(True); ba = b.clone().requires_grad_(True)
+    out = F.relu(F.linear(xa.double(), wa.double(), ba.double())) * mask.double()
+    gy = torch.randn(rows, cout, generator=g)
+    out.backward(gy.double())
+    xg = bigd[:, cin:].detach().requires_grad_(True)
+    wg = w.to(dev).requires_grad_(True); bg = b.to(dev).requires_grad_(True)
+    yo = ops.linear(xg, wg, bg, relu=True, mask=mask.to(dev))
+    yo.backward(gy.to(dev))
+    check("small-M linear dx", xg.grad.cpu(), xa.grad, 2e-5)
+    check("small-M linear dw", wg.grad.cpu(), wa.grad, 2e-5)
+    check("small-M linear db", bg.grad.cpu(), ba.grad, 2e-5)
+
+
 @pytest.mark.parametrize("M,C", [(50, 64), (3000, 256), (7, 2048)])
 def test_batchnorm_train(edrl, dev, M, C):
     from edrl_amd_pkg import encoders
