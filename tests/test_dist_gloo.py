@@ -100,3 +100,33 @@ def test_gradsync_world2_matches_single_process():
                 if p.grad is None:
                     continue
                 torch.testing.assert_close(torch.from_numpy(res[step][n]), p.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_gradsync_rejects_second_backward_outside_no_sync():
+    """a second backward() between zero_grad() and finish() outside no_sync() would add gradients on top of an
+    already exchanged (averaged) bucket and the ranks would diverge silently; GradSync raises instead.  Inside no_sync() the
+    same pattern is gradient accumulation and is exchanged once at finish().  (No process group: single replica, CPU.)"""
+    import edrl_amd
+    torch.manual_seed(0)
+    net = Net()
+    live = [p for n, p in net.named_parameters() if not n.startswith("dead")]
+    sync = edrl_amd.GradSync(net, bucket_mb=0.001, params=live)
+    x = torch.randn(8, 16)
+    sync.zero_grad()
+    net(x).sum().backward()
+    with pytest.raises(RuntimeError, match="already exchanged"):
+        net(x).sum().backward()
+    sync.finish()
+    # accumulation the supported way: both backward passes land in the buckets, one exchange
+    sync.zero_grad()
+    with sync.no_sync():
+        net(x).sum().backward()
+    net(x).sum().backward()
+    sync.finish()
+    ref = Net()
+    ref.load_state_dict(net.state_dict())
+    (ref(x).sum() * 2).backward()
+    for (n, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+        if r.grad is not None and not n.startswith("dead"):
+            torch.testing.assert_close(p.grad, r.grad, rtol=1e-5, atol=1e-6)
+    assert sync.collectives_issued == 0            # one replica: nothing to exchange unless force_collective
