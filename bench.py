@@ -218,7 +218,9 @@ def main():
                 avg_ms = dom["ms"] / dom["launches"]
                 peak = PEAK_BF16_MFMA_TFLOPS if enc_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
                 res["roofline"] = {
-                    "kernel": ("conv_gather_bf16_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x16_bf16)"
+                    "kernel": ("conv_gather_bf16 family (implicit-GEMM conv fwd+dgrad): conv_gather_bf16_v3_kernel (256x256 LDS-DMA core, "
+                               "v_mfma_f32_16x16x32_bf16: K-heavy layers) + conv_gather_bf16_kernel (128-row, v_mfma_f32_32x32x16_bf16: "
+                               "HBM-bound and fused-BatchNorm layers)"
                                if enc_dtype == "bf16" else
                                "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)"),
                     "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": peak,
@@ -248,7 +250,8 @@ def main():
                 if enc_dtype == "bf16":
                     res["roofline"]["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
                                                "HBM-bound (50-250 FLOP/B against a ~450 FLOP/B ridge), only the 3x3 layers of "
-                                               "stages 2-4 are MFMA-bound (~790 TFLOP/s there): profiles/README.md")
+                                               "stages 2-4 and the 1x1 layers with >= 1024 input channels are MFMA-bound "
+                                               "(v3 core: 0.95-1.15 PFLOP/s there): profiles/r03_v3_layers_bf16_2112img.txt")
             res["kernels"] = {}
             for k, v in ks.items():
                 e = {"launches": v["launches"], "calls": v["calls"], "ms_total": round(v["ms"], 3)}
