@@ -29,7 +29,7 @@ def timeit(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-MODES = {"old": {"EDRL_BF16_V3": "0", "EDRL_V3_STAGGER": "0", "EDRL_V3_PERSIST": "1"}, "v3": {"EDRL_BF16_V3": "2", "EDRL_V3_STAGGER": "0", "EDRL_V3_PERSIST": "1"}, "v3tile": {"EDRL_BF16_V3": "2", "EDRL_V3_STAGGER": "0", "EDRL_V3_PERSIST": "0"}}
+MODES = {"old": {"EDRL_BF16_V3": "0", "EDRL_V3_STAGGER": "0"}, "v3": {"EDRL_BF16_V3": "2", "EDRL_V3_STAGGER": "0"}, "v3stag": {"EDRL_BF16_V3": "2", "EDRL_V3_STAGGER": "1"}}
 
 
 def setmode(m):
@@ -54,7 +54,7 @@ def run(mode, fn):
     return o
 
 
-print(f"{'layer':20s} {'GFLOP':>7s} | fwd ms (TF): 128-row kernel, v3 (persistent), v3 one tile per workgroup | dgrad ms (TF): same three | max rel diff vs the 128-row kernel: fwd v3/v3tile, stats (v3tile), dgrad v3/v3tile")
+print(f"{'layer':20s} {'GFLOP':>7s} | fwd ms (TF): 128-row kernel, v3, v3 staggered | dgrad ms (TF): same three | max rel diff vs the 128-row kernel: fwd v3/stag, stats, dgrad v3/stag")
 tot = {}
 for name, Ci, H, Co, k, s, p, cnt in L:
     if only and only not in name:
@@ -70,8 +70,8 @@ for name, Ci, H, Co, k, s, p, cnt in L:
     f = lambda: ops.conv2d_fwd_bf16(x, wb, s, p, stats=True)
     d = lambda: ops.conv2d_dgrad_bf16(dy, wt, tuple(x.shape), s, p, out=dx)
     rel = lambda a, b: float((a.float() - b.float()).abs().max() / b.float().abs().max())
-    y0, st0, _ = run("old", f); y16, st16, _ = run("v3", f); y32, st32, _ = run("v3tile", f)
-    run("old", d); d0 = dx.clone(); run("v3", d); d16 = dx.clone(); run("v3tile", d)
+    y0, st0, _ = run("old", f); y16, st16, _ = run("v3", f); y32, st32, _ = run("v3stag", f)
+    run("old", d); d0 = dx.clone(); run("v3", d); d16 = dx.clone(); run("v3stag", d)
     errs = f"{rel(y16, y0):.1e}/{rel(y32, y0):.1e}, {rel(st32[:, :2], st0[:, :2]):.1e}, {rel(d16, d0):.1e}/{rel(dx, d0):.1e}"
     tf = ab(f); td = ab(d)
     T = lambda t: flop / t / 1e9
