@@ -434,6 +434,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TR* __restrict__ x,
       st4<TA>(out + (ii >> lg) * ld + c, v);
     };
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (C4 <= 256) {
+      // Block-contiguous chunks of 4 x 256 float4 (16 KiB per operand, all 8 loads of a thread in flight before the first use) --
+      // the shape torch's own vectorised elementwise kernels stream at ~6 TB/s for a 2-read : 1-write mix on this GPU
+      // (scripts/hbm_probe2.py); the column group (i & (C4-1)) is the thread's for every chunk because C4 divides 256.
+      const long cstride = (long)gridDim.x * 1024;
+      for (long base = (long)blockIdx.x * 1024; base < total; base += cstride) {
+        long ii[4]; f32x4 xv[4], rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ii[u] = base + u * 256 + threadIdx.x;
+          const bool ok = ii[u] < total;
+          xv[u] = ok ? ld4<TR>(x + (ii[u] >> lg) * ld + c) : z4;
+          rv[u] = (ok && residual) ? ld4<TA>(residual + (ii[u] >> lg) * ld + c) : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ii[u] < total) one(ii[u], xv[u], rv[u]);
+      }
+      return;
+    }
     for (; i + gstride < total; i += 2 * gstride) {
       const long j = i + gstride;
       const f32x4 x0 = ld4<TR>(x + (i >> lg) * ld + c), x1 = ld4<TR>(x + (j >> lg) * ld + c);
@@ -878,6 +898,14 @@ __global__ __launch_bounds__(256) void bcast_axis1_kernel(const float* __restric
   }
 }
 
+// bn_apply_kernel: one workgroup per 1024-float4 chunk, up to 64 workgroups per CU in the queue (the chunked fast path loops
+// beyond that)
+static inline int bn_apply_grid(long total) {
+  long b = (total + 1023) / 1024;
+  if (b > 256 * 64) b = 256 * 64;
+  if (b < 1) b = 1;
+  return (int)b;
+}
 static inline int ew_grid(long total) {
   long b = (total + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -1188,7 +1216,7 @@ int edrl_bn_apply_f32(const float* x, const float* mean, const float* scale, con
                       hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3) || (ld & 3)) return EDRL_EINVAL;
   if (relu_mask && ld != C) return EDRL_EINVAL;   // the byte mask is dense [M][C/4]
-  hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, mean, scale, shift, residual,
+  hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(bn_apply_grid(M * (C / 4))), dim3(256), 0, st, x, mean, scale, shift, residual,
                      out, relu_mask, M, C, ld, relu);
   EDRL_LAUNCH_CHECK();
   return 0;
@@ -1223,7 +1251,7 @@ int edrl_bn_bwd_f32(const float* dout, const float* out, const unsigned char* re
 int edrl_bn_apply_res_f32(const float* x, const float* fcoef, const float* residual, const float* res_fcoef, float* out,
                           unsigned char* relu_mask, long M, int C, int relu, hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3) || !x || !fcoef || !out) return EDRL_EINVAL;
-  hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, x, fcoef,
+  hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(bn_apply_grid(M * (C / 4))), dim3(256), 0, st, x, fcoef,
                      fcoef + 2 * (long)C, fcoef + 3 * (long)C, residual, out, relu_mask, M, C, (long)C, relu, res_fcoef);
   EDRL_LAUNCH_CHECK();
   return 0;
@@ -1426,7 +1454,7 @@ int edrl_bn_apply_mx(const void* x, int raw_bf16, const float* mean, const float
                      const void* residual, void* out, int act_bf16, unsigned char* relu_mask, long M, int C, int relu,
                      hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
-  const dim3 grid(ew_grid(M * (C / 4)));
+  const dim3 grid(bn_apply_grid(M * (C / 4)));
   if (raw_bf16 && act_bf16 && (C & 7) == 0)
     hipLaunchKernelGGL(bn_apply_h8_kernel, dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)x, mean, scale, shift,
                        (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, relu);
