@@ -982,6 +982,10 @@ __device__ __forceinline__ void ld8f(const float* p, float* o) {
   for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
 }
 
+// Both h8 elementwise kernels: when C/8 is a power of two <= 256 (every ResNet width) a thread keeps ONE column group, so the
+// per-channel coefficients are loaded once, the row index is a shift, and a workgroup streams block-contiguous chunks of 4 x 256
+// 16-byte groups with all of a thread's loads in flight before the first use (the shape that reaches ~6 TB/s here,
+// scripts/hbm_probe2.py); the arithmetic is unchanged (bit-identical results).  Other widths take the grid-stride loop.
 __global__ __launch_bounds__(256) void bn_apply_h8_kernel(const __bf16* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const __bf16* __restrict__ residual, __bf16* __restrict__ out,
@@ -989,20 +993,13 @@ __global__ __launch_bounds__(256) void bn_apply_h8_kernel(const __bf16* __restri
                                                           const float* __restrict__ res_coef = nullptr) {
   const int C8 = C >> 3;
   const long total = M * C8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / C8;
-    const int c = (int)(i - r * C8) * 8;
-    float xv[8], mu[8], sc[8], sf[8], v[8];
-    ld8h(x + r * C + c, xv);
-    ld8f(mean + c, mu); ld8f(scale + c, sc); ld8f(shift + c, sf);
+  auto one = [&](long i, long r, int c, const float* xv, float* rv, const float* mu, const float* sc, const float* sf,
+                 const float* rm, const float* rsc, const float* rsf) {
+    float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (xv[e] - mu[e]) * sc[e] + sf[e];
     if (residual) {
-      float rv[8];
-      ld8h(residual + r * C + c, rv);
       if (res_coef) {      // the residual is the raw downsample-branch output: its BatchNorm is applied here
-        float rm[8], rsc[8], rsf[8];
-        ld8f(res_coef + c, rm); ld8f(res_coef + 2 * (long)C + c, rsc); ld8f(res_coef + 3 * (long)C + c, rsf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) rv[e] = (rv[e] - rm[e]) * rsc[e] + rsf[e];
       }
@@ -1020,6 +1017,48 @@ __global__ __launch_bounds__(256) void bn_apply_h8_kernel(const __bf16* __restri
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     st8h(out + r * C + c, v);
+  };
+  if ((C8 & (C8 - 1)) == 0 && C8 <= 256) {
+    const int lg = __builtin_ctz(C8);
+    const int c = (int)(threadIdx.x & (C8 - 1)) * 8;
+    float mu[8], sc[8], sf[8], rm[8], rsc[8], rsf[8];
+    ld8f(mean + c, mu); ld8f(scale + c, sc); ld8f(shift + c, sf);
+    if (residual && res_coef) { ld8f(res_coef + c, rm); ld8f(res_coef + 2 * (long)C + c, rsc); ld8f(res_coef + 3 * (long)C + c, rsf); }
+    const long cstride = (long)gridDim.x * 1024;
+    for (long base = (long)blockIdx.x * 1024; base < total; base += cstride) {
+      bf16x8 xb[4], rb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i < total) {
+          xb[u] = *reinterpret_cast<const bf16x8*>(x + (i >> lg) * C + c);
+          if (residual) rb[u] = *reinterpret_cast<const bf16x8*>(residual + (i >> lg) * C + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i < total) {
+          float xv[8], rv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xv[e] = (float)xb[u][e]; rv[e] = residual ? (float)rb[u][e] : 0.f; }
+          one(i, i >> lg, c, xv, rv, mu, sc, sf, rm, rsc, rsf);
+        }
+      }
+    }
+    return;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C8;
+    const int c = (int)(i - r * C8) * 8;
+    float xv[8], mu[8], sc[8], sf[8], rv[8], rm[8], rsc[8], rsf[8];
+    ld8h(x + r * C + c, xv);
+    ld8f(mean + c, mu); ld8f(scale + c, sc); ld8f(shift + c, sf);
+    if (residual) {
+      ld8h(residual + r * C + c, rv);
+      if (res_coef) { ld8f(res_coef + c, rm); ld8f(res_coef + 2 * (long)C + c, rsc); ld8f(res_coef + 3 * (long)C + c, rsf); }
+    }
+    one(i, r, c, xv, rv, mu, sc, sf, rm, rsc, rsf);
   }
 }
 
@@ -1031,19 +1070,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const __bf16* __re
                                                               __bf16* __restrict__ dres, long M, int C) {
   const int C8 = C >> 3;
   const long total = M * C8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / C8;
-    const int c = (int)(i - r * C8) * 8;
-    float g[8], xv[8], mu[8], rs[8], c1[8], c2[8], gm[8], d[8];
-    ld8h(dout + r * C + c, g);
-    ld8h(x + r * C + c, xv);
+  auto one = [&](long i, long r, int c, float* g, const float* xv, int mb, const float* mu, const float* rs, const float* c1,
+                 const float* c2, const float* gm) {
+    float d[8];
     if (rmask) {
-      const int mb = *reinterpret_cast<const unsigned short*>(rmask + i * 2);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = (mb >> (e < 4 ? e : e + 4)) & 1 ? g[e] : 0.f;
     }
-    ld8f(mean + c, mu); ld8f(rstd + c, rs); ld8f(coef + c, c1); ld8f(coef + C + c, c2);
-    if (gamma) ld8f(gamma + c, gm);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float xh = (xv[e] - mu[e]) * rs[e];
@@ -1051,6 +1084,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const __bf16* __re
     }
     if (dres) st8h(dres + r * C + c, g);
     st8h(dx + r * C + c, d);
+  };
+  if ((C8 & (C8 - 1)) == 0 && C8 <= 256) {
+    const int lg = __builtin_ctz(C8);
+    const int c = (int)(threadIdx.x & (C8 - 1)) * 8;
+    float mu[8], rs[8], c1[8], c2[8], gm[8];
+    ld8f(mean + c, mu); ld8f(rstd + c, rs); ld8f(coef + c, c1); ld8f(coef + C + c, c2);
+    if (gamma) ld8f(gamma + c, gm);
+    const long cstride = (long)gridDim.x * 1024;
+    for (long base = (long)blockIdx.x * 1024; base < total; base += cstride) {
+      bf16x8 gb[4], xb[4];
+      int mbs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        mbs[u] = 0;
+        if (i < total) {
+          gb[u] = *reinterpret_cast<const bf16x8*>(dout + (i >> lg) * C + c);
+          xb[u] = *reinterpret_cast<const bf16x8*>(x + (i >> lg) * C + c);
+          if (rmask) mbs[u] = *reinterpret_cast<const unsigned short*>(rmask + i * 2);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i < total) {
+          float g[8], xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { g[e] = (float)gb[u][e]; xv[e] = (float)xb[u][e]; }
+          one(i, i >> lg, c, g, xv, mbs[u], mu, rs, c1, c2, gm);
+        }
+      }
+    }
+    return;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C8;
+    const int c = (int)(i - r * C8) * 8;
+    float g[8], xv[8], mu[8], rs[8], c1[8], c2[8], gm[8];
+    ld8h(dout + r * C + c, g);
+    ld8h(x + r * C + c, xv);
+    const int mb = rmask ? *reinterpret_cast<const unsigned short*>(rmask + i * 2) : 0;
+    ld8f(mean + c, mu); ld8f(rstd + c, rs); ld8f(coef + c, c1); ld8f(coef + C + c, c2);
+    if (gamma) ld8f(gamma + c, gm);
+    one(i, r, c, g, xv, mb, mu, rs, c1, c2, gm);
   }
 }
 
@@ -1456,7 +1533,7 @@ int edrl_bn_apply_mx(const void* x, int raw_bf16, const float* mean, const float
   if (M <= 0 || C <= 0 || (C & 3)) return EDRL_EINVAL;
   const dim3 grid(bn_apply_grid(M * (C / 4)));
   if (raw_bf16 && act_bf16 && (C & 7) == 0)
-    hipLaunchKernelGGL(bn_apply_h8_kernel, dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)x, mean, scale, shift,
+    hipLaunchKernelGGL(bn_apply_h8_kernel, dim3(bn_apply_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)x, mean, scale, shift,
                        (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, relu);
   else if (raw_bf16 && act_bf16)
     hipLaunchKernelGGL((bn_apply_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)x, mean, scale, shift,
@@ -1505,7 +1582,7 @@ static int bn_bwd_h8_impl(const __bf16* dout, const unsigned char* relu_mask, co
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M, dgamma,
                      dbeta, 0, coef);
   EDRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_apply_h8_kernel, dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, dout, relu_mask, x, save_mean,
+  hipLaunchKernelGGL(bn_bwd_apply_h8_kernel, dim3(bn_apply_grid(M * (C / 8))), dim3(256), 0, st, dout, relu_mask, x, save_mean,
                      save_rstd, gamma, coef, dx, dres, M, C);
   EDRL_LAUNCH_CHECK();
   return 0;
@@ -1533,7 +1610,7 @@ int edrl_bn_bwd_mx(const void* dout, int act_bf16, const unsigned char* relu_mas
 int edrl_bn_apply_res_bf16(const void* x, const float* fcoef, const void* residual, const float* res_fcoef, void* out,
                            unsigned char* relu_mask, long M, int C, int relu, hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 7) || !x || !fcoef || !out) return EDRL_EINVAL;
-  hipLaunchKernelGGL(bn_apply_h8_kernel, dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)x, fcoef,
+  hipLaunchKernelGGL(bn_apply_h8_kernel, dim3(bn_apply_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)x, fcoef,
                      fcoef + 2 * (long)C, fcoef + 3 * (long)C, (const __bf16*)residual, (__bf16*)out, relu_mask, M, C, relu,
                      res_fcoef);
   EDRL_LAUNCH_CHECK();
