@@ -906,6 +906,10 @@ static inline int bn_apply_grid(long total) {
   if (b < 1) b = 1;
   return (int)b;
 }
+// colstat1_h8_kernel: 8-channel groups per workgroup (64 -> 512 channels; 16 when the grid would be under ~4 workgroups per CU)
+static inline int colstat_h8_groups(long chunks, int C) {
+  return (chunks * ((C + 511) / 512) < 1024 && C >= 256) ? 16 : 64;
+}
 static inline int ew_grid(long total) {
   long b = (total + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -1136,14 +1140,16 @@ __global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restri
                                                           const unsigned char* __restrict__ rmask,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           long M, int C, float* __restrict__ part,
-                                                          __bf16* __restrict__ gout = nullptr) {
+                                                          __bf16* __restrict__ gout = nullptr, int cgmax = 64) {
   __shared__ float sh[256 * 16];
   const int C8 = C >> 3;
-  const int CG = C8 < 64 ? C8 : 64;      // 8-channel groups per block (C8 is a power of two or the block tail is idle)
+  // 8-channel groups per block: 64 (512 channels) on big grids; 16 when the (chunks x C/512) grid would leave most CUs without
+  // enough waves (stage 3-4 tensors: ~100-400 chunks) -- 4x the workgroups, 16 rows of the chunk in parallel per workgroup
+  const int CG = C8 < cgmax ? C8 : cgmax;
   const int RL = 256 / CG;
   const int tid = threadIdx.x;
   const int cg = tid % CG, rl = tid / CG;
-  const int c = (blockIdx.y * 64 + cg) * 8;
+  const int c = (blockIdx.y * cgmax + cg) * 8;
   const long row0 = (long)blockIdx.x * BN_ROWS_PER_CHUNK;
   long row1 = row0 + BN_ROWS_PER_CHUNK;
   if (row1 > M) row1 = M;
@@ -1153,7 +1159,7 @@ __global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restri
   if (c < C && rl < RL) {
     float mu[8], rs[8];
     ld8f(mean + c, mu); ld8f(rstd + c, rs);
-    constexpr int U = 2;
+    constexpr int U = 4;          // rows in flight per thread (the running sums are still taken in row order)
     long r = row0 + rl;
     auto acc = [&](const float* xv, float* g, int mb, bool masked) {
 #pragma unroll
@@ -1576,8 +1582,11 @@ static int bn_bwd_h8_impl(const __bf16* dout, const unsigned char* relu_mask, co
   const size_t stats = edrl_bn_workspace_bytes(M, C);
   float* coef = workspace + stats / sizeof(float);
   const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
-  hipLaunchKernelGGL(colstat1_h8_kernel, dim3(chunks, edrl_cdiv(C, 512)), dim3(256), 0, st, x, dout, relu_mask, save_mean,
-                     save_rstd, M, C, workspace);
+  {
+    const int cgm = colstat_h8_groups(chunks, C);
+    hipLaunchKernelGGL(colstat1_h8_kernel, dim3(chunks, edrl_cdiv(C, cgm * 8)), dim3(256), 0, st, x, dout, relu_mask, save_mean,
+                       save_rstd, M, C, workspace, (__bf16*)nullptr, cgm);
+  }
   EDRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(edrl_cdiv(C, FIN_CH)), dim3(256), 0, st, workspace, chunks, C, M, dgamma,
                      dbeta, 0, coef);
@@ -1621,8 +1630,11 @@ int edrl_bn_bwd_reduce_bf16(const void* dout, const unsigned char* relu_mask, co
   if (M <= 0 || C <= 0 || (C & 7) || !dout || !x || !fcoef || !part) return EDRL_EINVAL;
   if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
   const int chunks = edrl_cdiv(M, BN_ROWS_PER_CHUNK);
-  hipLaunchKernelGGL(colstat1_h8_kernel, dim3(chunks, edrl_cdiv(C, 512)), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)dout,
-                     relu_mask, fcoef, fcoef + (long)C, M, C, part, (__bf16*)g_out);
+  {
+    const int cgm = colstat_h8_groups(chunks, C);
+    hipLaunchKernelGGL(colstat1_h8_kernel, dim3(chunks, edrl_cdiv(C, cgm * 8)), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)dout,
+                       relu_mask, fcoef, fcoef + (long)C, M, C, part, (__bf16*)g_out, cgm);
+  }
   EDRL_LAUNCH_CHECK();
   return 0;
 }
