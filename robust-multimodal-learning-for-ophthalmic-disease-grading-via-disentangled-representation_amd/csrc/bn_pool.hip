@@ -692,12 +692,22 @@ __global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const float* __rest
                                                              int W, int C, int Ho, int Wo) {
   const int C4 = C >> 2;
   const long total = (long)N * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long t = i / C4;
-    const int wo = (int)(t % Wo); t /= Wo;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+  // the (n, ho, wo, c) of a thread's element: decoded once (the only 64-bit divisions), then advanced by the grid stride with
+  // carries -- the stride is decomposed into (dn, dho, dwo, dc) up front
+  const long gs = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c4 = (int)(i % C4);
+  long t0 = i / C4;
+  int wo = (int)(t0 % Wo); t0 /= Wo;
+  int ho = (int)(t0 % Ho);
+  int n = (int)(t0 / Ho);
+  const int dc = (int)(gs % C4);
+  long t1 = gs / C4;
+  const int dwo = (int)(t1 % Wo); t1 /= Wo;
+  const int dho = (int)(t1 % Ho);
+  const int dn = (int)(t1 / Ho);
+  for (; i < total; i += gs) {
+    const int c = c4 * 4;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c);
     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -720,6 +730,10 @@ __global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const float* __rest
     }
     st4<TY>(y + i * 4, best);
     *reinterpret_cast<unsigned int*>(idx + i * 4) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+    c4 += dc; wo += dwo; ho += dho; n += dn;
+    if (c4 >= C4) { c4 -= C4; ++wo; }
+    if (wo >= Wo) { wo -= Wo; ++ho; }
+    if (ho >= Ho) { ho -= Ho; ++n; }
   }
 }
 
