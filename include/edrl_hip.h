@@ -208,6 +208,9 @@ int edrl_bn_apply_res_bf16(const void* x, const float* fcoef, const void* residu
                            unsigned char* relu_mask, long M, int C, int relu, hipStream_t stream);
 int edrl_bn_bwd_reduce_bf16(const void* dout, const unsigned char* relu_mask, const void* x, const float* fcoef, void* g_out,
                             float* part, size_t part_bytes, long M, int C, hipStream_t stream);
+/* d_raw (bf16) = A*g + nK2*x + C2 with bcoef [4][C]: the BatchNorm-backward apply step as a standalone pass, for a conv that takes
+ * d_raw on the plain kernels inside an otherwise fused block (the 3x3 layer of a bf16 bottleneck block). */
+int edrl_bn_draw_bf16(const void* g, const void* x, const float* bcoef, void* d_raw, long M, int C, hipStream_t stream);
 
 /* Mixed-precision BatchNorm apply / backward and max-pool of the bf16 (C2) trunk: raw_bf16 / act_bf16 give the storage type
  * (0 fp32, 1 bf16) of the raw conv output (+ its gradient) and of the activated tensors (+ their gradients); statistics,

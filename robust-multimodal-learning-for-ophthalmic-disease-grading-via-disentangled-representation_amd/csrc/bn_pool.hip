@@ -1149,6 +1149,51 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const __bf16* __re
   }
 }
 
+// d_raw = A*g + nK2*x + C2 (bcoef rows 0..2) as a standalone bf16 pass: what the fused conv kernels form in their operand loads,
+// materialised for a consumer that runs on the plain kernels (the 3x3 layer of a fused bf16 bottleneck block, encoders._KBF16.mid_sep).
+__global__ __launch_bounds__(256) void bn_draw_h8_kernel(const __bf16* __restrict__ g, const __bf16* __restrict__ x,
+                                                         const float* __restrict__ bcoef, __bf16* __restrict__ out, long M, int C) {
+  const int C8 = C >> 3;
+  const long total = M * C8;
+  auto one = [&](long r, int c, const bf16x8 gb, const bf16x8 xb, const float* A, const float* nK2, const float* C2) {
+    float d[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = __builtin_fmaf(nK2[e], (float)xb[e], __builtin_fmaf(A[e], (float)gb[e], C2[e]));
+    st8h(out + r * C + c, d);
+  };
+  if ((C8 & (C8 - 1)) == 0 && C8 <= 256) {
+    const int lg = __builtin_ctz(C8);
+    const int c = (int)(threadIdx.x & (C8 - 1)) * 8;
+    float A[8], nK2[8], C2[8];
+    ld8f(bcoef + c, A); ld8f(bcoef + (long)C + c, nK2); ld8f(bcoef + 2 * (long)C + c, C2);
+    const long cstride = (long)gridDim.x * 1024;
+    for (long base = (long)blockIdx.x * 1024; base < total; base += cstride) {
+      bf16x8 gb[4], xb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i < total) {
+          gb[u] = *reinterpret_cast<const bf16x8*>(g + (i >> lg) * C + c);
+          xb[u] = *reinterpret_cast<const bf16x8*>(x + (i >> lg) * C + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i < total) one(i >> lg, c, gb[u], xb[u], A, nK2, C2);
+      }
+    }
+    return;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C8;
+    const int c = (int)(i - r * C8) * 8;
+    float A[8], nK2[8], C2[8];
+    ld8f(bcoef + c, A); ld8f(bcoef + (long)C + c, nK2); ld8f(bcoef + 2 * (long)C + c, C2);
+    one(r, c, *reinterpret_cast<const bf16x8*>(g + r * C + c), *reinterpret_cast<const bf16x8*>(x + r * C + c), A, nK2, C2);
+  }
+}
+
 // (sum g, sum g*xhat) partials, g = dout * relu-mask: part[chunk][3][C] like colstat_kernel<1>
 __global__ __launch_bounds__(256) void colstat1_h8_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dout,
                                                           const unsigned char* __restrict__ rmask,
@@ -1649,6 +1694,15 @@ int edrl_bn_bwd_reduce_bf16(const void* dout, const unsigned char* relu_mask, co
     hipLaunchKernelGGL(colstat1_h8_kernel, dim3(chunks, edrl_cdiv(C, cgm * 8)), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)dout,
                        relu_mask, fcoef, fcoef + (long)C, M, C, part, (__bf16*)g_out, cgm);
   }
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// d_raw (bf16) = A*g + nK2*x + C2 with bcoef [4][C] (edrl_bn_bwd_finalize_partials_f32); g, x, d_raw dense [M][C] bf16, C % 8 == 0.
+int edrl_bn_draw_bf16(const void* g, const void* x, const float* bcoef, void* d_raw, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 7) || !g || !x || !bcoef || !d_raw) return EDRL_EINVAL;
+  hipLaunchKernelGGL(bn_draw_h8_kernel, dim3(bn_apply_grid(M * (C / 8))), dim3(256), 0, st, (const __bf16*)g, (const __bf16*)x, bcoef,
+                     (__bf16*)d_raw, M, C);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

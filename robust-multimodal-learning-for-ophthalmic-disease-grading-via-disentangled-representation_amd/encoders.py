@@ -183,6 +183,7 @@ class _K32:
     dgrad_bn = staticmethod(lambda *a, **k: ops.conv2d_dgrad_bn(*a, **k))
     apply_res_name, reduce_name, elt = "edrl_bn_apply_res_f32", "edrl_bn_bwd_reduce_f32", 4.0
     fuse_max_planes = 1 << 30        # every residual stage takes the fused-BatchNorm path
+    mid_sep = False                  # (bf16 only) the 3x3 layer of a fused bottleneck block on the plain kernels
     grad_in = staticmethod(lambda dout: dout.contiguous())
     feat_out = staticmethod(lambda cur: cur)
 
@@ -285,6 +286,13 @@ class _KBF16:
     # VALU-bound on the compute-heavy stages (profiles/r02_fused_layers_bf16_2112img.txt: stage-3/4 blocks lose 0.3-0.8 ms per
     # 2112 images, stage-1/2 blocks -- HBM-bound, wide BatchNorm tensors -- gain 0.7-2.5 ms), so only blocks up to this width fuse.
     fuse_max_planes = int(os.environ.get("EDRL_BF16_FUSE_MAXPLANES", "128"))
+    # Inside a fused bottleneck block the 3x3 layer is the one place where fusion LOSES at bf16 (its operand transforms are
+    # re-applied per tap: 26 vector instructions per MFMA, profiles/r03_pmc_traffic_c2.json; per layer sep 2.6 -> fused 3.2 ms,
+    # profiles/r02_fused_layers_bf16_2112img.txt), while the 1x1 layers around it win big.  mid_sep keeps the block fused but
+    # runs that one layer on the plain kernels: forward = one bn_apply pass (a1 + sign bytes) + plain conv; backward = d_raw
+    # materialised by edrl_bn_draw_bf16, plain weight / data gradient, and the standalone reduce that hands the masked gradient
+    # and the partial sums back to the fused chain (stride-1 blocks; the stride-2 block's reduce runs on the 4x larger map).
+    mid_sep = os.environ.get("EDRL_BF16_MID_SEP", "1") != "0"
     grad_in = staticmethod(lambda dout: ops.to_bf16(dout.contiguous()))
     feat_out = staticmethod(lambda cur: ops.to_f32(cur))
 
@@ -428,7 +436,18 @@ class _TrunkFn(torch.autograd.Function):
                     rec.update(cd=cd, fd=fd)
                 if T.kind == "bottleneck":
                     c1, f1 = cf(pre + ".conv1", pre + ".bn1", cur, None, 1, 0)
-                    c2, f2 = cf(pre + ".conv2", pre + ".bn2", c1, f1, s, 1)
+                    if K.mid_sep and s == 1:
+                        C1 = c1.shape[-1]
+                        M1 = c1.numel() // C1
+                        a1 = torch.empty_like(c1)
+                        k1 = torch.empty((M1, C1 // 4), device=c1.device, dtype=torch.uint8)
+                        L.call("edrl_bn_apply_mx", P(c1), 1, P(f1[0]), P(f1[2]), P(f1[3]), None, P(a1), 1, P(k1), M1, C1, 1)
+                        c2, f2 = cf(pre + ".conv2", pre + ".bn2", a1, None, s, 1)
+                        rec.update(a1=a1, k1=k1, mid_sep=True)
+                        if cap is not None:
+                            cap[pre + ".conv1"].update(out=a1, mask=k1)
+                    else:
+                        c2, f2 = cf(pre + ".conv2", pre + ".bn2", c1, f1, s, 1)
                     cl, fl = cf(pre + ".conv3", pre + ".bn3", c2, f2, 1, 0)
                     rec.update(c1=c1, f1=f1, c2=c2, f2=f2, c3=cl, f3=fl)
                     last = pre + ".conv3"
@@ -631,10 +650,25 @@ class _TrunkFn(torch.autograd.Function):
                     g2, part, chunks = fdgrad(last, gl, cl, bl, c2.shape, 1, 0, ep=(c2, None, f2, True),
                                               ep_keep=recompute_keep(c2, f2))
                     b2 = fin_bwd(pre + ".bn2", part, chunks, 2, c2, f2)
-                    fwgrad(pre + ".conv2", g2, c2, b2, c1, f1, s, 1)
-                    fcap(pre + ".conv2", pre + ".bn2", g2, c2, b2)
-                    g1, part, chunks = fdgrad(pre + ".conv2", g2, c2, b2, c1.shape, s, 1, ep=(c1, None, f1, True),
-                                              ep_keep=recompute_keep(c1, f1))
+                    planes1 = 2
+                    if rec.get("mid_sep"):
+                        C2c = c2.shape[-1]
+                        d2 = torch.empty_like(c2)
+                        L.call("edrl_bn_draw_bf16", P(g2), P(c2), P(b2), P(d2), c2.numel() // C2c, C2c)
+                        w2 = p[pre + ".conv2.weight"]
+                        grads[pre + ".conv2.weight"] = K.conv_wgrad(d2, rec["a1"], tuple(w2.shape), s, 1)
+                        da1 = K.conv_dgrad(d2, wt_of(pre + ".conv2"), tuple(c1.shape), s, 1)
+                        if cap is not None:
+                            cap["bwd:" + pre + ".bn2"] = dict(dout=g2.clone(), dgamma=grads[pre + ".bn2.weight"],
+                                                            dbeta=grads[pre + ".bn2.bias"], d_raw=d2, dres=None, masked=True)
+                            cap[pre + ".conv2"].update(d_raw=d2, dW=grads[pre + ".conv2.weight"], dx_before=None, dx_after=da1.clone())
+                        g1, part, chunks, planes1 = _bn_bwd_reduce(K, da1, rec["k1"], c1, f1, want_g=True)
+                        del d2, da1
+                    else:
+                        fwgrad(pre + ".conv2", g2, c2, b2, c1, f1, s, 1)
+                        fcap(pre + ".conv2", pre + ".bn2", g2, c2, b2)
+                        g1, part, chunks = fdgrad(pre + ".conv2", g2, c2, b2, c1.shape, s, 1, ep=(c1, None, f1, True),
+                                                  ep_keep=recompute_keep(c1, f1))
                     c1_stride, c1_pad = 1, 0
                 else:
                     fwgrad(last, gl, cl, bl, c1, f1, 1, 1)
@@ -642,7 +676,7 @@ class _TrunkFn(torch.autograd.Function):
                     g1, part, chunks = fdgrad(last, gl, cl, bl, c1.shape, 1, 1, ep=(c1, None, f1, True),
                                               ep_keep=recompute_keep(c1, f1))
                     c1_stride, c1_pad = s, 1
-                b1 = fin_bwd(pre + ".bn1", part, chunks, 2, c1, f1)
+                b1 = fin_bwd(pre + ".bn1", part, chunks, planes1 if bott else 2, c1, f1)
                 fwgrad(pre + ".conv1", g1, c1, b1, xin, None, c1_stride, c1_pad)
                 fcap(pre + ".conv1", pre + ".bn1", g1, c1, b1)
                 # block-input gradient: (downsample branch | identity) first, conv1's data gradient accumulated last so that

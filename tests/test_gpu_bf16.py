@@ -166,6 +166,21 @@ def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
     check("fused stem fwd vs torch", y32.permute(0, 3, 1, 2).cpu(), ref, 1e-6)
 
 
+def test_bn_draw_bf16_kernel(edrl, dev):
+    """edrl_bn_draw_bf16: d_raw = A*g + nK2*x + C2 per channel on bf16 tensors (fp32 arithmetic, one rounding), the standalone
+    form of what the fused consumers build in their operand loads -- power-of-two width (chunked path) and an odd one (generic)."""
+    L = edrl._lib
+    P = L.ptr
+    for M, C in ((3001, 128), (517, 24)):
+        g = torch.Generator().manual_seed(9)
+        gg = torch.randn(M, C, generator=g).bfloat16().to(dev); x = torch.randn(M, C, generator=g).bfloat16().to(dev)
+        bc = torch.randn(4, C, generator=g).to(dev)
+        out = torch.empty_like(gg)
+        L.call("edrl_bn_draw_bf16", P(gg), P(x), P(bc), P(out), M, C)
+        ref = (bc[0].double() * gg.double() + bc[1].double() * x.double() + bc[2].double())
+        check(f"bn_draw_bf16 {M}x{C}", out.float().cpu(), ref.cpu(), BF16_TOL)
+
+
 def test_conv_bf16_exact_on_small_integers(edrl, dev):
     """Operand-layout check that cannot hide behind a tolerance: sparse 0/±1 data keeps every sum a small integer,
     exactly representable in bf16, so the result must be bit-exact."""
