@@ -1006,8 +1006,11 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
                                    int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
                                    int flags, const void* ep_raw, const unsigned char* ep_mask, const float* ep_fcoef,
                                    int ep_relu, float* ep_part, size_t ep_part_bytes, hipStream_t st) {
-  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || !g_in || !yraw ||
-      !bcoef || (Co % HBK) || (Ci % 4))
+  // yraw == NULL && bcoef == NULL: `g_in` already IS d_raw (materialised by edrl_bn_draw_bf16) -- plain operand load, epilogue only
+  // (needs ep_raw: without it this is edrl_conv2d_nhwc_dgrad_bf16)
+  const bool plain_in = !yraw && !bcoef;
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || !g_in ||
+      (!plain_in && (!yraw || !bcoef)) || (plain_in && !ep_raw) || (Co % HBK) || (Ci % 4))
     return EDRL_EINVAL;
   if (((uintptr_t)g_in & 15) || ((uintptr_t)yraw & 15) || ((uintptr_t)wt & 15) || ((uintptr_t)dx & 7)) return EDRL_EINVAL;
   if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
@@ -1049,8 +1052,9 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
       g.M = (int)((long)N * g.OHs * g.OWs);
       if (g.Ktot == 0 && (flags & GF_ACCUM) && !ep_raw) continue;
       F.ep_chunk0 = chunk0;
-      const int rc = ep_raw ? dispatch_gather_fused_bf16<true, 2, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)
-                            : dispatch_gather_fused_bf16<true, 2, 0>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st);
+      const int rc = plain_in ? dispatch_gather_fused_bf16<true, 0, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)
+                     : ep_raw ? dispatch_gather_fused_bf16<true, 2, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)
+                              : dispatch_gather_fused_bf16<true, 2, 0>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st);
       if (rc) return rc;
       chunk0 += (g.M + 127) / 128;
     }

@@ -657,13 +657,15 @@ class _TrunkFn(torch.autograd.Function):
                         L.call("edrl_bn_draw_bf16", P(g2), P(c2), P(b2), P(d2), c2.numel() // C2c, C2c)
                         w2 = p[pre + ".conv2.weight"]
                         grads[pre + ".conv2.weight"] = K.conv_wgrad(d2, rec["a1"], tuple(w2.shape), s, 1)
-                        da1 = K.conv_dgrad(d2, wt_of(pre + ".conv2"), tuple(c1.shape), s, 1)
+                        # plain operand (d2 is materialised), epilogue as in the fused chain: masked with bn1's sign bytes,
+                        # (sum g, sum g*x) partials out -- no standalone reduce pass over da1
+                        g1, part, chunks = K.dgrad_bn(d2, None, None, wt_of(pre + ".conv2"), tuple(c1.shape), s, 1,
+                                                      ep=(c1, rec["k1"], f1, True))
                         if cap is not None:
                             cap["bwd:" + pre + ".bn2"] = dict(dout=g2.clone(), dgamma=grads[pre + ".bn2.weight"],
                                                             dbeta=grads[pre + ".bn2.bias"], d_raw=d2, dres=None, masked=True)
-                            cap[pre + ".conv2"].update(d_raw=d2, dW=grads[pre + ".conv2.weight"], dx_before=None, dx_after=da1.clone())
-                        g1, part, chunks, planes1 = _bn_bwd_reduce(K, da1, rec["k1"], c1, f1, want_g=True)
-                        del d2, da1
+                            cap[pre + ".conv2"].update(d_raw=d2, dW=grads[pre + ".conv2.weight"], dx_before=None, dx_after=g1.clone())
+                        del d2
                     else:
                         fwgrad(pre + ".conv2", g2, c2, b2, c1, f1, s, 1)
                         fcap(pre + ".conv2", pre + ".bn2", g2, c2, b2)
