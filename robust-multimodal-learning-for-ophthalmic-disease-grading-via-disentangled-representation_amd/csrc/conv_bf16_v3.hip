@@ -430,8 +430,11 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
     if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[1] = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);
   } else {
+    // Diagnostic builds (wrong or absent outputs by construction) need an explicit second switch so that a stray EDRL_V3_DBG in a
+    // production environment cannot silently corrupt a run.
     const char* de = getenv("EDRL_V3_DBG");
-    const int dbg = de ? atoi(de) : 0;
+    const char* da = getenv("EDRL_ALLOW_DIAGNOSTIC_KERNELS");
+    const int dbg = (de && da && atoi(da) == 1) ? atoi(de) : 0;
     if (dbg >= 1 && dbg <= 4) {     // diagnostic builds: 1 cache-resident loads, 2 no DMA, 3 / 4 in-kernel stamps
       auto kd = dbg == 1 ? conv_gather_bf16_v3_kernel<false, 1> : (dbg == 2 ? conv_gather_bf16_v3_kernel<false, 2> : (dbg == 3 ? conv_gather_bf16_v3_kernel<false, 3> : conv_gather_bf16_v3_kernel<false, 4>));
       (void)hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
