@@ -11,7 +11,7 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-os.environ["EDRL_BF16_V3"] = "2"
+os.environ["EDRL_BF16_V3"] = "2"; os.environ["EDRL_ALLOW_DIAGNOSTIC_KERNELS"] = "1"
 for name, Ci, H, Co, k, s, p in [("l3 3x3 256", 256, 14, 256, 3, 1, 1), ("l4 3x3 512", 512, 7, 512, 3, 1, 1), ("l4 1x1 2048-512", 2048, 7, 512, 1, 1, 0), ("l3 1x1 1024-256", 1024, 14, 256, 1, 1, 0)]:
     x = torch.randn(N, H, H, Ci, device=dev).bfloat16()
     wb = (torch.randn(Co, k, k, Ci, device=dev) * 0.05).bfloat16()
