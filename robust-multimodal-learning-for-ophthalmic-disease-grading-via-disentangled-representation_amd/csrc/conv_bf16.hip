@@ -289,8 +289,40 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
       e_shift2 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + n);
     }
   }
+  constexpr int NT = 32 / RPP2;       // row passes per 32-row tile
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    // Every global operand of this 32-row tile's epilogue (the accumulate target, the raw tensor of the BatchNorm below and its
+    // sign bytes) is requested up front -- NT loads in flight per lane behind the LDS transpose instead of one exposed HBM round
+    // trip per row pass (the expanding 1x1 data gradients of stages 1-2, K = 64 / 128, are all epilogue: 2.7 -> TB/s figures in
+    // DESIGN.md section 3b).
+    long pixs[NT];
+    bool oks[NT];
+    bf16x4 o_pre[NT], x_pre[NT];
+    int mb_pre[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int row = t * RPP2 + srow;
+      const long m = m0 + wm0 + i * 32 + row;
+      oks[t] = m < g.M && n < g.NC;
+      long pix = m;
+      if (DGRAD && g.step > 1 && oks[t]) {
+        const int ohw = g.OHs * g.OWs;
+        const int nn = (int)(m / ohw);
+        const int rem = (int)(m - (long)nn * ohw);
+        const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+        pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+      }
+      pixs[t] = pix;
+      mb_pre[t] = 0;
+      if (oks[t]) {
+        if (accum) o_pre[t] = *reinterpret_cast<const bf16x4*>(dst + pix * g.ld_dst + n);
+        if constexpr (EPI == 1) {
+          x_pre[t] = *reinterpret_cast<const bf16x4*>((const __bf16*)F.ep_x + pix * F.ld_ep + n);
+          if (F.ep_mask) mb_pre[t] = F.ep_mask[pix * (long)(g.NC >> 2) + (n >> 2)];
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -301,33 +333,22 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(stage + sc4 * 4);
 #pragma unroll
-    for (int t = 0; t < 32 / RPP2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int row = t * RPP2 + srow;
-      const long m = m0 + wm0 + i * 32 + row;
-      if (m < g.M && n < g.NC) {
-        long pix = m;
-        if (DGRAD && g.step > 1) {
-          const int ohw = g.OHs * g.OWs;
-          const int nn = (int)(m / ohw);
-          const int rem = (int)(m - (long)nn * ohw);
-          const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
-          pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
-        }
+      if (oks[t]) {
         f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SLD + sc4 * 4);
         if (stats) { const f32x4 d = v - kshift; st0 += d; st1 += d * d; }
-        __bf16* p = dst + pix * g.ld_dst + n;
+        __bf16* p = dst + pixs[t] * g.ld_dst + n;
         if (accum) {
-          const bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
+          for (int e = 0; e < 4; ++e) v[e] += (float)o_pre[t][e];
         }
         if constexpr (EPI == 1) {
-          const bf16x4 xb = *reinterpret_cast<const bf16x4*>((const __bf16*)F.ep_x + pix * F.ld_ep + n);
           f32x4 xr;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xr[e] = (float)xb[e];
+          for (int e = 0; e < 4; ++e) xr[e] = (float)x_pre[t][e];
           if (F.ep_mask) {
-            const int mb = F.ep_mask[pix * (long)(g.NC >> 2) + (n >> 2)];
+            const int mb = mb_pre[t];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (mb >> e) & 1 ? v[e] : 0.f;
           } else if (g.flags & GF_EPI_RELU) {
