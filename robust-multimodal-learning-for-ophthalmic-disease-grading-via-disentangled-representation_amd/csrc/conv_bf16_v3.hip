@@ -357,26 +357,32 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
     const bool accum = g.flags & GF_ACCUM;
     const int rr = tid >> 5, c = tid & 31;
     const int n = n0 + c * 8;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 16 + rr;
-      const long m = m0 + row;
-      if (m < g.M && n < g.NC) {
-        long pix = m;
-        if (DGRAD && g.step > 1) {
-          const int nn = (int)(m / ohw);
-          const int rem = (int)(m - (long)nn * ohw);
-          const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
-          pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
-        }
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * 512 + ((c ^ rr) << 4));
-        __bf16* p = dst + pix * g.ld_dst + n;
-        if (accum) {
-          const bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
+    long pixs[16];
+    bf16x8 opre[16];
+    // destination rows first; when accumulating, all 16 read-modify-write operands of the thread are requested up front
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)o[e]);
+    for (int it = 0; it < 16; ++it) {
+      const long m = m0 + it * 16 + rr;
+      long pix = m;
+      if (DGRAD && g.step > 1 && m < g.M) {
+        const int nn = (int)(m / ohw);
+        const int rem = (int)(m - (long)nn * ohw);
+        const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+        pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+      }
+      pixs[it] = (m < g.M && n < g.NC) ? pix : -1;
+      if (accum && pixs[it] >= 0) opre[it] = *reinterpret_cast<const bf16x8*>(dst + pix * g.ld_dst + n);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      if (pixs[it] >= 0) {
+        const int row = it * 16 + rr;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * 512 + ((c ^ rr) << 4));
+        if (accum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)opre[it][e]);
         }
-        *reinterpret_cast<bf16x8*>(p) = v;
+        *reinterpret_cast<bf16x8*>(dst + pixs[it] * g.ld_dst + n) = v;
       }
     }
   }
