@@ -906,7 +906,9 @@ int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N,
 size_t edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW) {
   int splits, tps;
   wgrad_plan_h((long)N * Ho * Wo, Co, KH * KW * Ci, &splits, &tps);
-  return (size_t)splits * Co * KH * KW * Ci * sizeof(float);
+  const size_t a = (size_t)splits * Co * KH * KW * Ci * sizeof(float);
+  const size_t b = wgrad_bf16_v3_workspace_bytes(N, Ho, Wo, Co, Ci, KH, KW);     // either core may serve the call
+  return a > b ? a : b;
 }
 }  // extern "C"
 
@@ -934,6 +936,15 @@ static int wgrad_bf16_impl(const void* dy, const void* x, float* dw, float* work
       (Ci % 8))
     return EDRL_EINVAL;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return EDRL_EINVAL;
+  if (!fuse && wgrad_bf16_v3_ok(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)) {     // wide plain layers: 256x256 LDS-DMA core
+    int splits3 = 0;
+    const int rc = launch_wgrad_bf16_v3(dy, x, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, &splits3, st);
+    if (rc) return rc;
+    const long n3 = (long)Co * KH * KW * Ci;
+    hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(n3, 1024)), dim3(256), 0, st, workspace, dw, n3, splits3, accumulate);
+    EDRL_LAUNCH_CHECK();
+    return 0;
+  }
   WgradGeomH g;
   g.P = (long)N * Ho * Wo;
   g.OH = Ho; g.OW = Wo; g.Co = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;

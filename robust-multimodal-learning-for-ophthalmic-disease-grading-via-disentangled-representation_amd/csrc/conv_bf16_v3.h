@@ -7,3 +7,10 @@
 bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad);
 // forward (dgrad = false) or data gradient (one parity class per call) of the plain bf16 convolution; honours GF_STATS / GF_ACCUM.
 int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st);
+
+// Plain bf16 weight gradient on the 256x256 LDS-DMA core (conv_wgrad_bf16_v3.hip): writes `*splits_out` fp32 partial slabs
+// [split][Co][KH*KW*Ci] into `workspace`; the caller reduces them (splitk_reduce_h_kernel).
+bool wgrad_bf16_v3_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad);
+size_t wgrad_bf16_v3_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW);
+int launch_wgrad_bf16_v3(const void* dy, const void* x, float* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int Ci,
+                         int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int* splits_out, hipStream_t st);

@@ -28,6 +28,7 @@
 #include <string.h>
 #include <type_traits>
 #include "conv_bf16_v3.h"
+#include "lds_dma.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -41,26 +42,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define V3_UNIT (V3_ABYTES + V3_BBYTES)    // 32 KiB
 #define V3_SLOTS 4
 #define V3_LDS (V3_SLOTS * V3_UNIT)        // 128 KiB = the epilogue's [256][256] bf16 image
-
-typedef int v3_i32x4 __attribute__((ext_vector_type(4)));
-// Raw buffer descriptor (base, stride 0, num_records = bytes, gfx9 dword3 0x00020000) from wave-uniform values, as an SGPR quad
-// for inline asm.
-__device__ __forceinline__ v3_i32x4 v3_make_srd(const void* base, unsigned bytes) {
-  const unsigned long a = (unsigned long)base;
-  v3_i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-// One LDS-DMA piece (64 lanes x 16 bytes -> 1 KiB of LDS at `lds`, wave-uniform) issued from inline asm: hipcc does not see it, so
-// it neither counts it in vmcnt nor inserts its own conservative "LDS write pending" waits in front of ds_reads when the loop
-// body has control flow (the builtin form made it drain vmcnt inside the staggered loop); every wait is placed by hand below.
-// M0 carries the LDS destination and is written in the same statement (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void v3_dma16(unsigned lds, unsigned voff, v3_i32x4 srd, int soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
 
 // G[(r>>2)&3] of the header: {0,2,3,1}
 __device__ __forceinline__ int v3_swz(int r) {

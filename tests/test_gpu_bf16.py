@@ -124,6 +124,54 @@ def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
         check(f"v3 vs v2 conv_dgrad{case}", dv, outs["0"][2], BF16_TOL)
 
 
+W3_CASES = [
+    # N, Ci, H, W, Co, k, s, p : both channel counts multiples of 256 (the v3 weight-gradient core's domain); pixel counts that
+    # are not multiples of the 32-pixel unit, fewer units than the 3-deep prefetch, padding taps, stride 2 (odd sizes: the last
+    # input row / column is never read), several tiles along both output axes, images shorter than one unit (4 x 3 = 12 pixels)
+    (3, 256, 14, 14, 256, 3, 1, 1),
+    (2, 256, 13, 11, 512, 3, 2, 1),
+    (5, 256, 9, 7, 256, 1, 1, 0),
+    (2, 512, 10, 10, 256, 1, 2, 0),
+    (1, 256, 7, 7, 256, 3, 1, 1),
+    (7, 1024, 4, 3, 256, 1, 1, 0),
+    (40, 256, 7, 7, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", W3_CASES)
+def test_conv_wgrad_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
+    """The 256x256 LDS-DMA weight-gradient core (csrc/conv_wgrad_bf16_v3.hip: transposing LDS reads of DMA-written pixel-major
+    images, X-row offsets decoded once per workgroup into an LDS table), forced on (EDRL_BF16_WGRAD_V3=2) far below its production
+    range, against the fp64 weight gradient of the same bf16 operands (fp32 result: only fp32 accumulation error, 2e-5 of the
+    output's max, as the 128x128 kernel), against that kernel (EDRL_BF16_WGRAD_V3=0; different split plan, so not bit-identical),
+    accumulating into an existing gradient, and run-to-run deterministic."""
+    ops = edrl.ops
+    N, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(35)
+    x = torch.randn(N, H, W, Ci, generator=g).bfloat16()
+    w = (torch.randn(Co, k, k, Ci, generator=g) * 0.1).bfloat16()
+    xd = nchw(x.double())
+    wd = w.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.conv2d(xd, wd, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.double())
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    xh = x.to(dev)
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("EDRL_BF16_WGRAD_V3", mode)
+        dw = ops.conv2d_wgrad_bf16(dyh, xh, (Co, k, k, Ci), s, p)
+        dw_again = ops.conv2d_wgrad_bf16(dyh, xh, (Co, k, k, Ci), s, p)
+        dwa = ops.conv2d_wgrad_bf16(dyh, xh, (Co, k, k, Ci), s, p, out=dw.clone(), accumulate=True)
+        torch.cuda.synchronize()
+        assert torch.equal(dw, dw_again), "deterministic split-K"
+        outs[mode] = (dw.cpu(), dwa.cpu())
+    dv, dav = outs["2"]
+    check(f"v3 conv_wgrad{case}", dv.permute(0, 3, 1, 2), wd.grad, 2e-5)
+    check(f"v3 conv_wgrad_accum{case}", dav.permute(0, 3, 1, 2), 2 * wd.grad, 4e-5)
+    check(f"v3 vs v2 conv_wgrad{case}", dv, outs["0"][0], 4e-5)
+
+
 def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
     """The bf16 trunk's stem (BatchNorm + ReLU folded into the 3x3/s2 max-pool, edrl_maxpool3x3s2_bn_*_mx): the pooled tensor is
     the fp32 kernel's result rounded to bf16 ONCE (bit-exact), the arg-max bytes are identical, and the two backward kernels fed
