@@ -51,6 +51,13 @@ long edrl_conv_stats_chunks(int N, int Ho, int Wo);
 int edrl_conv2d_nhwc_fwd_stats_f32(const float* x, const float* w, float* y, const float* stat_shift, float* stat_part,
                                    size_t stat_part_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                                    int KH, int KW, int stride, int pad, hipStream_t stream);
+/* The same contraction (fp32 operands, fp32 MFMA, fp32 chunk partials from the accumulators) with y stored as bf16: the stem of
+ * the bf16 trunk (fp32 image in, bf16 raw tensor out; replaces the reference trunk's first nn.Conv2d under bf16 storage, SURVEY.md
+ * section 8a rows E1/E2).  Ho / Wo are the caller's (the space-to-depth stem pads bottom / right by one less).  Ci % 4 == 0,
+ * Co % 4 == 0. */
+int edrl_conv2d_nhwc_fwd_stats_f32_obf16(const float* x, const float* w, void* y_bf16, float* stat_part, size_t stat_part_bytes,
+                                         int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride,
+                                         int pad, hipStream_t stream);
 
 /* Data gradient (autograd of the above): dx [+]= conv_transpose(dy, w).
  * wt is w permuted to [Ci,KH,KW,Co] by edrl_permute_weight_f32. */
@@ -182,14 +189,17 @@ int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* id
                                         size_t part_bytes, int N, int H, int W, int C, hipStream_t stream);
 int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef,
                                        const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t stream);
-/* The same three with the pooled tensor (y) / its gradient (dy) stored as bf16 when the flag is 1: the stem of the bf16 trunk
- * (C2/C4; the raw stem conv output, the statistics and d_raw stay fp32). */
-int edrl_maxpool3x3s2_bn_fwd_mx(const float* x, const float* fcoef, void* y, int y_bf16, unsigned char* idx, int N, int H, int W,
-                                int C, hipStream_t stream);
-int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
-                                       float* part, size_t part_bytes, int N, int H, int W, int C, hipStream_t stream);
-int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
-                                      const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t stream);
+/* The same three with the pooled tensor (y) / its gradient (dy) stored as bf16 when y_bf16 / dy_bf16 is 1, and the raw stem conv
+ * output x stored as bf16 when x_bf16 is 1 (needs the other flag too): the stem of the bf16 trunk (C2/C4; the statistics and
+ * d_raw, which feeds the fp32 stem weight gradient, stay fp32). */
+int edrl_maxpool3x3s2_bn_fwd_mx(const void* x, int x_bf16, const float* fcoef, void* y, int y_bf16, unsigned char* idx, int N, int H,
+                                int W, int C, hipStream_t stream);
+int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsigned char* idx, const void* x, int x_bf16,
+                                       const float* fcoef, float* part, size_t part_bytes, int N, int H, int W, int C,
+                                       hipStream_t stream);
+int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const void* x, int x_bf16,
+                                      const float* fcoef, const float* bcoef, float* d_raw, int N, int H, int W, int C,
+                                      hipStream_t stream);
 
 /* bf16 counterparts of the fused-BatchNorm entry points (conv_bf16.hip / bn_pool.hip): bf16 tensors, fp32 coefficient arrays
  * fcoef [5][C] / bcoef [4][C] and fp32 partial sums; same contracts as the _f32 versions above.  Ci % 32 == 0, Co % 32 == 0. */

@@ -98,8 +98,10 @@ def conv_bn_bf16_op(x, w, gamma, beta, stride, pad, relu, residual=None):
 def trunk_forward_bf16(x, sd, kind, blocks):
     """Storage-aware restatement of the product's bf16 trunk (encoders._TrunkBf16Fn, SURVEY.md §8a rows E1/E2 at
     C2/C4): same topology as trunk_forward, with a bf16 rounding at exactly the tensors the product stores in bf16
-    (conv_bn_bf16_op).  The stem conv and all BatchNorm arithmetic stay in the working precision.  Training-mode batch
-    statistics only (running statistics are not touched).  Autograd sees straight-through roundings."""
+    (conv_bn_bf16_op).  The stem conv (fp32 image and weights in the product) and all BatchNorm arithmetic stay in the working
+    precision; the stem's raw output is stored as bf16 like every other layer's (statistics from the unrounded values, as the
+    product takes them from the fp32 accumulators).  Training-mode batch statistics only (running statistics are not touched).
+    Autograd sees straight-through roundings."""
     def cb(x, cname, bname, stride, pad, relu, residual=None):
         return conv_bn_bf16_op(x, sd[cname + ".weight"], sd[bname + ".weight"], sd[bname + ".bias"], stride, pad, relu,
                                residual)[1]
@@ -107,7 +109,7 @@ def trunk_forward_bf16(x, sd, kind, blocks):
     a = _conv(x, sd, "conv1", 2, 3)
     mean = a.mean(dim=(0, 2, 3), keepdim=True)
     var = a.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
-    a = (a - mean) * torch.rsqrt(var + 1e-5) * sd["bn1.weight"].view(1, -1, 1, 1) + sd["bn1.bias"].view(1, -1, 1, 1)
+    a = (_q16(a) - mean) * torch.rsqrt(var + 1e-5) * sd["bn1.weight"].view(1, -1, 1, 1) + sd["bn1.bias"].view(1, -1, 1, 1)
     x = F.max_pool2d(_q16(F.relu(a)), 3, 2, 1)
     for blk in blocks:
         pre, s = blk["name"], blk["stride"]

@@ -686,8 +686,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v4_kernel(const T* __res
 // (gather form: an input pixel collects dy of every window whose arg-max tap points at it) and the ReLU decision from the raw
 // tensor: MODE 0 reduces (sum g, sum g*xhat) per 1024-pixel chunk [chunk][3][C] (colstat layout), MODE 1 writes
 // d_raw = A*g + nK2*x + C2.  fcoef [5][C], bcoef [4][C] as in the fused conv kernels.
-template <typename TY>
-__global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ fcoef,
+template <typename TY, typename TX = float>
+__global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ fcoef,
                                                              TY* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
                                                              int W, int C, int Ho, int Wo) {
   const int C4 = C >> 2;
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const float* __rest
       for (int kw = 0; kw < 3; ++kw) {
         const int w = wo * 2 - 1 + kw;
         if (w < 0 || w >= W) continue;
-        const f32x4 v = edrl_bn_relu2(*reinterpret_cast<const f32x4*>(x + (((long)n * H + h) * W + w) * C + c), sc, sh);
+        const f32x4 v = edrl_bn_relu2(ld4<TX>(x + (((long)n * H + h) * W + w) * C + c), sc, sh);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (!any || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
@@ -775,9 +775,9 @@ __device__ __forceinline__ f32x4 maxpool_bn_gather_g(const TY* __restrict__ dy, 
 }
 
 #define MPB_ROWS_PER_BLOCK 512     // MODE 1: pixels per workgroup
-template <int MODE, typename TY>
+template <int MODE, typename TY, typename TX = float>
 __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const TY* __restrict__ dy, const unsigned char* __restrict__ idx,
-                                                             const float* __restrict__ x, const float* __restrict__ fcoef,
+                                                             const TX* __restrict__ x, const float* __restrict__ fcoef,
                                                              const float* __restrict__ bcoef, float* __restrict__ part,
                                                              float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
   // Both modes: grid (row chunks, C/256 column blocks); a workgroup walks a CONTIGUOUS pixel range with CG = min(C/4, 64) column
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const TY* __restric
     const long t = r / W;
     int h = (int)(t % H), n = (int)(t / H);
     for (; r < row1; r += RL) {
-      const f32x4 xr = *reinterpret_cast<const f32x4*>(x + r * C + c);
+      const f32x4 xr = ld4<TX>(x + r * C + c);
       const f32x4 g = maxpool_bn_gather_g<TY>(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo);
       if (MODE == 1) {
         *reinterpret_cast<f32x4*>(dx + r * C + c) = edrl_bn_bwd_dx2(g, xr, p0, p1, p2);
@@ -1497,63 +1497,77 @@ int edrl_bn_train_stats_fcoef_f32(const float* x, long M, int C, const float* ga
 }
 // Stem max-pool with the BatchNorm + ReLU of its input folded in (x = RAW stem conv output [N,H,W,C], fcoef [5][C]):
 // y [N,Ho,Wo,C] = maxpool3x3/s2/p1(relu(x*scale + shift2)), idx = arg-max tap bytes.
-int edrl_maxpool3x3s2_bn_fwd_mx(const float* x, const float* fcoef, void* y, int y_bf16, unsigned char* idx, int N, int H, int W, int C,
-                                hipStream_t st) {
-  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef) return EDRL_EINVAL;
+// _mx: x_bf16 = 1: the raw stem output is a bf16 tensor (the bf16 trunk's stem, edrl_conv2d_nhwc_fwd_stats_f32_obf16; needs
+// y_bf16 = 1); y_bf16 = 1: the pooled tensor is bf16.
+int edrl_maxpool3x3s2_bn_fwd_mx(const void* x, int x_bf16, const float* fcoef, void* y, int y_bf16, unsigned char* idx, int N, int H,
+                                int W, int C, hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || (x_bf16 && !y_bf16)) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(ew_grid((long)N * Ho * Wo * (C / 4)));
-  if (y_bf16)
-    hipLaunchKernelGGL(maxpool_bn_fwd_kernel<__bf16>, grid, dim3(256), 0, st, x, fcoef, (__bf16*)y, idx, N, H, W, C, Ho, Wo);
+  if (x_bf16)
+    hipLaunchKernelGGL((maxpool_bn_fwd_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)x, fcoef, (__bf16*)y, idx, N, H, W,
+                       C, Ho, Wo);
+  else if (y_bf16)
+    hipLaunchKernelGGL(maxpool_bn_fwd_kernel<__bf16>, grid, dim3(256), 0, st, (const float*)x, fcoef, (__bf16*)y, idx, N, H, W, C, Ho, Wo);
   else
-    hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, grid, dim3(256), 0, st, x, fcoef, (float*)y, idx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, fcoef, (float*)y, idx, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
 int edrl_maxpool3x3s2_bn_fwd_f32(const float* x, const float* fcoef, float* y, unsigned char* idx, int N, int H, int W, int C,
                                  hipStream_t st) {
-  return edrl_maxpool3x3s2_bn_fwd_mx(x, fcoef, y, 0, idx, N, H, W, C, st);
+  return edrl_maxpool3x3s2_bn_fwd_mx(x, 0, fcoef, y, 0, idx, N, H, W, C, st);
 }
 // Its backward in two launches (the max-pool gradient and the ReLU decision are rebuilt on the fly in both):
 //   _reduce: partial sums (sum g, sum g*xhat) -> part [ceil(N*H*W/1024)][3][C] (planes = 3 for edrl_bn_bwd_finalize_partials_f32)
 //   _apply : d_raw [N,H,W,C] = A*g + nK2*x + C2 with bcoef [4][C]
-// _mx: the pooled tensor's gradient dy is bf16 (dy_bf16 = 1, the bf16 trunk) or fp32; the raw stem output and d_raw stay fp32.
-int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
-                                       float* part, size_t part_bytes, int N, int H, int W, int C, hipStream_t st) {
-  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !part) return EDRL_EINVAL;
+// _mx: the pooled tensor's gradient dy is bf16 (dy_bf16 = 1, the bf16 trunk) or fp32; the raw stem output x is bf16 with
+// x_bf16 = 1 (needs dy_bf16 = 1); d_raw stays fp32 (it feeds the fp32 stem weight gradient).
+int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsigned char* idx, const void* x, int x_bf16,
+                                       const float* fcoef, float* part, size_t part_bytes, int N, int H, int W, int C,
+                                       hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !part || (x_bf16 && !dy_bf16)) return EDRL_EINVAL;
   const long M = (long)N * H * W;
   if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256));
-  if (dy_bf16)
-    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, x, fcoef,
+  if (x_bf16)
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, __bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x,
+                       fcoef, (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
+  else if (dy_bf16)
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const float*)x, fcoef,
                        (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
   else
-    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, float>), grid, dim3(256), 0, st, (const float*)dy, idx, x, fcoef,
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, float>), grid, dim3(256), 0, st, (const float*)dy, idx, (const float*)x, fcoef,
                        (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
 int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef, float* part,
                                         size_t part_bytes, int N, int H, int W, int C, hipStream_t st) {
-  return edrl_maxpool3x3s2_bn_bwd_reduce_mx(dy, 0, idx, x, fcoef, part, part_bytes, N, H, W, C, st);
+  return edrl_maxpool3x3s2_bn_bwd_reduce_mx(dy, 0, idx, x, 0, fcoef, part, part_bytes, N, H, W, C, st);
 }
-int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const float* x, const float* fcoef,
-                                      const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t st) {
-  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !bcoef || !d_raw) return EDRL_EINVAL;
+int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const void* x, int x_bf16,
+                                      const float* fcoef, const float* bcoef, float* d_raw, int N, int H, int W, int C,
+                                      hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !bcoef || !d_raw || (x_bf16 && !dy_bf16)) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(edrl_cdiv((long)N * H * W, MPB_ROWS_PER_BLOCK), edrl_cdiv(C, 256));
-  if (dy_bf16)
-    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, x, fcoef, bcoef,
+  if (x_bf16)
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x,
+                       fcoef, bcoef, (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
+  else if (dy_bf16)
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const float*)x, fcoef, bcoef,
                        (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
   else
-    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, float>), grid, dim3(256), 0, st, (const float*)dy, idx, x, fcoef, bcoef,
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, float>), grid, dim3(256), 0, st, (const float*)dy, idx, (const float*)x, fcoef, bcoef,
                        (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
 int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef,
                                        const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t st) {
-  return edrl_maxpool3x3s2_bn_bwd_apply_mx(dy, 0, idx, x, fcoef, bcoef, d_raw, N, H, W, C, st);
+  return edrl_maxpool3x3s2_bn_bwd_apply_mx(dy, 0, idx, x, 0, fcoef, bcoef, d_raw, N, H, W, C, st);
 }
 
 int edrl_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st) {

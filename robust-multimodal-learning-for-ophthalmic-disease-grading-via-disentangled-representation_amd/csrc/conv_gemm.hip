@@ -255,6 +255,18 @@ __device__ __forceinline__ u32x4 edrl_rsrc_words(const void* base, unsigned byte
 __device__ __forceinline__ void edrl_buffer_store_b128_soff(f32x4 v, u32x4 rs, unsigned voff, int soff) {
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 7" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 g_bf16x4 __attribute__((ext_vector_type(4)));
+// the same for 4 bf16 values (OUT16: the tile is stored rounded to bf16)
+__device__ __forceinline__ void edrl_buffer_store_b64_soff(u32x2 v, u32x4 rs, unsigned voff, int soff) {
+  asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 7" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x2 edrl_pack_bf16x4(f32x4 v) {
+  g_bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+  return __builtin_bit_cast(u32x2, o);
+}
 
 // BUF (FAST only; host-checked footprints < 2 GiB): both operands come through buffer descriptors -- the gathered one
 // through a per-workgroup descriptor based at the first image the tile's rows touch -- so masked rows / taps are an
@@ -272,11 +284,17 @@ __device__ __forceinline__ void edrl_buffer_store_b128_soff(f32x4 v, u32x4 rs, u
 //          per-tile partial sums (sum g, sum g*xhat) of that BatchNorm's backward -- no separate reduction pass.
 // MASK (ATR != 0): the geometry has padding taps / masked rows that must read as exactly 0 AFTER the transform (false for
 // 1x1 / pad-0 layers, whose only invalid rows are rows >= M of the last tile: those are never stored).
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true>
+// OUT16 (forward, EPI 0, vector epilogue, no accumulate / multiplier): `dst` is a bf16 tensor -- the fp32 result is rounded once
+// on the way out (BatchNorm partials still come from the fp32 accumulators).  The bf16 trunk's stem: fp32 image in, fp32 MFMA,
+// bf16 raw tensor out like every other layer of that trunk.
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
+          bool OUT16 = false>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherFuse F) {
   static_assert(ATR == 0 || BUF, "operand transforms ride on the buffer-descriptor path");
+  static_assert(!OUT16 || (EPI == 0 && !DGRAD), "bf16 output: plain forward only");
+  constexpr unsigned EB = OUT16 ? 2u : 4u;     // bytes per destination element
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDKT = BKT + 4;
@@ -641,20 +659,21 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
           const int nl = (int)(((unsigned long long)(unsigned)(m0 + BM - 1) * g.mg_ohw) >> g.sh_ohw);
           pix0 = (long)nf * g.OH * g.OW; colb = 0; span = (unsigned)(nl - nf + 1) * (unsigned)(g.OH * g.OW);
         } else { pix0 = m0 + wrow0; colb = n0 + (wv & 1) * WN; span = WM; }
-        const u32x4 ws_d = edrl_rsrc_words(dst + pix0 * g.ld_dst + colb, span * (unsigned)g.ld_dst * 4u);
-        const __amdgpu_buffer_rsrc_t rs_d =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(dst + pix0 * g.ld_dst + colb), 0, (int)(span * (unsigned)g.ld_dst * 4u), 0x00020000);
+        void* dbase = OUT16 ? (void*)((__bf16*)dst + pix0 * g.ld_dst + colb) : (void*)(dst + pix0 * g.ld_dst + colb);
+        const u32x4 ws_d = edrl_rsrc_words(dbase, span * (unsigned)g.ld_dst * EB);
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, (int)(span * (unsigned)g.ld_dst * EB), 0x00020000);
         __amdgpu_buffer_rsrc_t rs_x, rs_k;
         if constexpr (EPI != 0)
           rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)F.ep_x + pix0 * F.ld_ep + colb), 0,
                                                    (int)(span * (unsigned)F.ld_ep * 4u), 0x00020000);
         if constexpr (EPI == 2)
           rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)(F.ep_mask + pix0 * nq + (colb >> 2)), 0, (int)(span * (unsigned)nq), 0x00020000);
-        const int ldd4 = (int)g.ld_dst * 4, ldx4 = (int)F.ld_ep * 4;
+        const int ldd4 = (int)g.ld_dst * (int)EB, ldx4 = (int)F.ld_ep * 4;
         // lane offsets (non-strided: fixed; strided: column part here, pixel part per row group)
         const unsigned cd = colok ? (unsigned)((S ? n : sc4 * 4) * 4) : OOBE;
+        const unsigned cdd = colok ? (unsigned)(S ? n : sc4 * 4) * EB : OOBE;     // (destination: EB bytes per element)
         const unsigned ck = colok ? (unsigned)(S ? (n >> 2) : sc4) : OOBE;
-        const unsigned vd = cd + (S ? 0u : (unsigned)(srow * ldd4));
+        const unsigned vd = cdd + (S ? 0u : (unsigned)(srow * ldd4));
         const unsigned vx = cd + (S ? 0u : (unsigned)(srow * ldx4));
         const unsigned vk = ck + (S ? 0u : (unsigned)(srow * nq));
         f32x4 xr[EPI != 0 ? NT : 1], old[EPI == 2 ? NT : 1];
@@ -703,7 +722,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
               const f32x4 d = v - kshift;
               st0 += d;
               st1 = __builtin_elementwise_fma(d, d, st1);
-              edrl_buffer_store_b128_soff(v, ws_d, od(t), so(t, RPP2 * ldd4));
+              if constexpr (OUT16) edrl_buffer_store_b64_soff(edrl_pack_bf16x4(v), ws_d, od(t), so(t, RPP2 * ldd4));
+              else edrl_buffer_store_b128_soff(v, ws_d, od(t), so(t, RPP2 * ldd4));
             }
           } else {
 #pragma unroll
@@ -726,7 +746,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
                 st0 += v;
                 st1 = __builtin_elementwise_fma(v, xr[t], st1);
               }
-              edrl_buffer_store_b128_soff(v, ws_d, od(t), so(t, RPP2 * ldd4));
+              if constexpr (OUT16) edrl_buffer_store_b64_soff(edrl_pack_bf16x4(v), ws_d, od(t), so(t, RPP2 * ldd4));
+              else edrl_buffer_store_b128_soff(v, ws_d, od(t), so(t, RPP2 * ldd4));
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -767,6 +788,10 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           if (mul) v *= *reinterpret_cast<const f32x4*>(mul + pix * g.ld_aux + n);
+          if constexpr (OUT16) {      // (host-checked: no accumulate, no EPI)
+            *reinterpret_cast<u32x2*>((__bf16*)dst + pix * g.ld_dst + n) = edrl_pack_bf16x4(v);
+            continue;
+          }
           float* p = dst + pix * g.ld_dst + n;
           if (accum) v += *reinterpret_cast<const f32x4*>(p);
           if constexpr (EPI != 0) {
@@ -881,7 +906,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   }
 }
 
-template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true>
+template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
+          bool OUT16 = false>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
                             const float* mul, const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
@@ -889,7 +915,7 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI, MASK>;
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI, MASK, OUT16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1598,6 +1624,32 @@ int edrl_conv2d_nhwc_fwd_stats_f32(const float* x, const float* w, float* y, con
   g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
   g.stat_part = stat_part; g.stat_shift = stat_shift;
   return dispatch_gather<false>(x, w, y, nullptr, nullptr, g, st);
+}
+
+// The same contraction (fp32 operands, fp32 MFMA, fp32 BatchNorm partials from the accumulators) with the result stored as bf16:
+// the stem of the bf16 trunk (fp32 image in, bf16 raw tensor out -- half the bytes for the passes that follow).  Ho / Wo are the
+// caller's (asymmetric bottom / right padding of the space-to-depth stem: ops.stem_conv_fwd).  Ci % 4 == 0, Co % 4 == 0.
+int edrl_conv2d_nhwc_fwd_stats_f32_obf16(const float* x, const float* w, void* y_bf16, float* stat_part, size_t stat_part_bytes,
+                                         int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride,
+                                         int pad, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+      pad < 0 || (Ci % 4) || (Co % 4) || !stat_part)
+    return EDRL_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y_bf16 & 7)) return EDRL_EINVAL;
+  if ((long)N * Ho * Wo > 0x7fffffffL) return EDRL_EINVAL;
+  if ((long)(Ho - 1) * stride - pad + KH - 1 > (long)Hi - 1 + pad) return EDRL_EINVAL;
+  if (stat_part_bytes < (size_t)edrl_conv_stats_chunks(N, Ho, Wo) * 3 * Co * sizeof(float)) return EDRL_ENOSPC;
+  GatherGeom g;
+  g.M = (int)((long)N * Ho * Wo);
+  g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_src = Ci; g.ld_dst = Co; g.ld_aux = 0; g.flags = GF_STATS | GF_VEC_EPI;
+  g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
+  g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
+  g.stat_part = stat_part; g.stat_shift = nullptr;
+  if (Co <= 64)
+    return launch_gather_v2<128, 64, false, 16, 3, false, false, 0, 0, true, true>(x, w, (float*)y_bf16, nullptr, nullptr, g, st);
+  return launch_gather_v2<128, 128, false, 16, 3, false, false, 0, 0, true, true>(x, w, (float*)y_bf16, nullptr, nullptr, g, st);
 }
 
 // Convolution data gradient: dx[n,hi,wi,ci] (+)= sum dy[n,ho,wo,co] * wt[ci,kh,kw,co]

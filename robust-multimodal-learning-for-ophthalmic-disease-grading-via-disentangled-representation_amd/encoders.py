@@ -115,6 +115,7 @@ def _bn_bwd(dout, mask, raw, mean, rstd, gamma, want_dres):
 # A block whose layer geometries lack the fused fast paths (edrl_conv2d_fused_ok_f32: tiny / odd maps) keeps the separate
 # passes; the gradient handed from block to block is ("plain", dout) or ("masked", g, part, chunks, planes).
 _FUSE_BN = os.environ.get("EDRL_FUSE_BN", "1") != "0"
+_STEM_RAW16 = os.environ.get("EDRL_BF16_STEM_RAW16", "1") != "0"    # (bf16 trunk) raw stem conv output stored as bf16, statistics from the conv epilogue
 _FUSE_STEM = os.environ.get("EDRL_FUSE_STEM", "1") != "0"      # BatchNorm + ReLU of the stem folded into its max-pool (fp32 trunk)
 
 
@@ -301,11 +302,24 @@ class _KBF16:
         """fp32 stem conv + fp32 statistics, bf16 activation out.  Default (EDRL_FUSE_STEM): BatchNorm + ReLU folded into the
         max-pool as in the fp32 trunk -- the pool reads the RAW fp32 conv output and writes the bf16 pooled tensor; the activated
         112^2 tensor, its sign bytes and (in backward) its gradient never exist."""
+        bn = bnd("bn1", p)
+        if _FUSE_STEM and cap is None and _STEM_S2D and _STEM_RAW16:
+            # the raw stem output is a bf16 tensor like every other layer's (fp32 image, fp32 MFMA, one rounding on the way out);
+            # its statistics come from the conv epilogue's fp32 partials -- no separate statistics pass over the largest tensor
+            raw, part, chunks, x, folded = ops.stem_conv_fwd_obf16(x, p["conv1.weight"])
+            N, H, W, C = raw.shape
+            M = N * H * W
+            fc = _fcoef_from_partials(part, chunks, M, C, bn)
+            Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            p0 = torch.empty((N, Ho, Wo, C), device=raw.device, dtype=torch.bfloat16)
+            idx = torch.empty((N, Ho, Wo, C), device=raw.device, dtype=torch.uint8)
+            ops.call_timed_bytes("maxpool_bn_fwd", M * C * 2.0 + p0.numel() * 3.0, "edrl_maxpool3x3s2_bn_fwd_mx", P(raw), 1, P(fc), P(p0),
+                                 1, P(idx), N, H, W, C)
+            return p0, ("fused", x, folded, raw, fc, idx)
         if _STEM_S2D:
             raw, x, folded = ops.stem_conv_fwd(x, p["conv1.weight"])
         else:
             raw, folded = ops.conv2d_fwd(x, p["conv1.weight"], stride=2, pad=3), False
-        bn = bnd("bn1", p)
         C = raw.shape[-1]
         M = raw.numel() // C
         dev = raw.device
@@ -318,7 +332,7 @@ class _KBF16:
                    P(bn["running_var"]), float(bn["momentum"]), float(bn["eps"]), P(fc), P(ws), nbytes)
             p0 = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.bfloat16)
             idx = torch.empty((N, Ho, Wo, C), device=dev, dtype=torch.uint8)
-            ops.call_timed_bytes("maxpool_bn_fwd", M * C * 4.0 + p0.numel() * 3.0, "edrl_maxpool3x3s2_bn_fwd_mx", P(raw), P(fc), P(p0), 1,
+            ops.call_timed_bytes("maxpool_bn_fwd", M * C * 4.0 + p0.numel() * 3.0, "edrl_maxpool3x3s2_bn_fwd_mx", P(raw), 0, P(fc), P(p0), 1,
                                  P(idx), N, H, W, C)
             return p0, ("fused", x, folded, raw, fc, idx)
         m0 = torch.empty(C, device=dev, dtype=torch.float32)
@@ -341,13 +355,15 @@ class _KBF16:
             N, H, W, C = raw.shape
             M = N * H * W
             ws, nbytes = _bn_ws(M, C, raw.device)
-            ops.call_timed_bytes("maxpool_bn_bwd", M * C * 4.0 + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dcur), 1,
-                                 P(idx), P(raw), P(fc), P(ws), nbytes, N, H, W, C)
+            r16 = 1 if raw.dtype == torch.bfloat16 else 0
+            relt = 2.0 if r16 else 4.0
+            ops.call_timed_bytes("maxpool_bn_bwd", M * C * relt + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dcur), 1,
+                                 P(idx), P(raw), r16, P(fc), P(ws), nbytes, N, H, W, C)
             bc, dg, db = _bcoef_from_partials(ws, (M + 1023) // 1024, 3, M, p["bn1.weight"], fc)
             grads["bn1.weight"], grads["bn1.bias"] = dg, db
-            draw = torch.empty_like(raw)                               # fp32 gradient for the fp32 stem weight gradient
-            ops.call_timed_bytes("maxpool_bn_bwd", M * C * 8.0 + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dcur), 1,
-                                 P(idx), P(raw), P(fc), P(bc), P(draw), N, H, W, C)
+            draw = torch.empty(raw.shape, device=raw.device, dtype=torch.float32)    # fp32 gradient for the fp32 stem weight gradient
+            ops.call_timed_bytes("maxpool_bn_bwd", M * C * (4.0 + relt) + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dcur), 1,
+                                 P(idx), P(raw), r16, P(fc), P(bc), P(draw), N, H, W, C)
             grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), folded)
             return None
         x, folded, raw, a0_shape, m0, r0, k0, idx = stem

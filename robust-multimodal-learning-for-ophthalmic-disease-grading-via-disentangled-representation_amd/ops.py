@@ -213,6 +213,29 @@ def stem_conv_fwd(x, w):
     return conv2d_fwd(x, w, stride=2, pad=3), x, False
 
 
+def stem_conv_fwd_obf16(x, w):
+    """The stem conv of the bf16 trunk: fp32 image and weights, fp32 MFMA, result stored as bf16, BatchNorm chunk partials
+    from the fp32 accumulators.  -> (y bf16 [N,H/2,W/2,Co], part [chunks][3][Co], chunks, tensor kept for the weight gradient,
+    folded flag); same two geometries as stem_conv_fwd."""
+    N, H, W, C = x.shape
+    Co = w.shape[0]
+    if (H % 2 == 0) and (W % 2 == 0) and tuple(w.shape[1:3]) == (7, 7):
+        xin, wk, stride, pad, Ho, Wo, folded = space_to_depth2(x), stem_weight_fold(w), 1, 2, H // 2, W // 2, True
+    else:
+        KH, KW = w.shape[1], w.shape[2]
+        xin, wk, stride, pad, folded = x, w, 2, 3, False
+        Ho, Wo = (H + 6 - KH) // 2 + 1, (W + 6 - KW) // 2 + 1
+    _, Hi, Wi, Ci = xin.shape
+    KH, KW = wk.shape[1], wk.shape[2]
+    out = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.bfloat16)
+    chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
+    part = torch.empty((chunks, 3, Co), device=x.device, dtype=torch.float32)
+    _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * 49 * C if folded else 2.0 * N * Ho * Wo * Co * KH * KW * Ci,
+                  "edrl_conv2d_nhwc_fwd_stats_f32_obf16", P(xin), P(wk), P(out), P(part), part.numel() * 4, N, Hi, Wi, Ci, Ho, Wo,
+                  Co, KH, KW, stride, pad, nbytes=4.0 * (xin.numel() + wk.numel()) + 2.0 * out.numel())
+    return out, part, chunks, xin, folded
+
+
 def stem_conv_wgrad(dy, x_saved, w_shape, folded):
     if not folded:
         return conv2d_wgrad(dy, x_saved, tuple(w_shape), 2, 3)

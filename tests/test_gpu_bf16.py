@@ -190,7 +190,7 @@ def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
     y32 = torch.empty(N, Ho, Wo, C, device=dev); i32 = torch.empty(N, Ho, Wo, C, device=dev, dtype=torch.uint8)
     y16 = torch.empty(N, Ho, Wo, C, device=dev, dtype=torch.bfloat16); i16 = torch.empty_like(i32)
     L.call("edrl_maxpool3x3s2_bn_fwd_f32", P(raw), P(fc), P(y32), P(i32), N, H, W, C)
-    L.call("edrl_maxpool3x3s2_bn_fwd_mx", P(raw), P(fc), P(y16), 1, P(i16), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_fwd_mx", P(raw), 0, P(fc), P(y16), 1, P(i16), N, H, W, C)
     assert torch.equal(y16, y32.bfloat16()) and torch.equal(i16, i32)
     dy16 = torch.randn(N, Ho, Wo, C, generator=g).bfloat16().to(dev)
     dy32 = dy16.float()
@@ -198,7 +198,7 @@ def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
     nb = L.query("edrl_bn_workspace_bytes", M, C)
     ws32 = torch.zeros(nb // 4, device=dev); ws16 = torch.zeros(nb // 4, device=dev)
     L.call("edrl_maxpool3x3s2_bn_bwd_reduce_f32", P(dy32), P(i32), P(raw), P(fc), P(ws32), nb, N, H, W, C)
-    L.call("edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dy16), 1, P(i32), P(raw), P(fc), P(ws16), nb, N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dy16), 1, P(i32), P(raw), 0, P(fc), P(ws16), nb, N, H, W, C)
     chunks = (M + 1023) // 1024
     assert torch.equal(ws16[:chunks * 3 * C].view(chunks, 3, C)[:, :2], ws32[:chunks * 3 * C].view(chunks, 3, C)[:, :2])
     bc = torch.empty(4, C, device=dev)
@@ -206,12 +206,60 @@ def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
     bc[2] = 0.01 * torch.randn(C, generator=g).to(dev); bc[3] = fc[0]
     d32 = torch.empty_like(raw); d16 = torch.empty_like(raw)
     L.call("edrl_maxpool3x3s2_bn_bwd_apply_f32", P(dy32), P(i32), P(raw), P(fc), P(bc), P(d32), N, H, W, C)
-    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw), P(fc), P(bc), P(d16), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw), 0, P(fc), P(bc), P(d16), N, H, W, C)
     assert torch.equal(d16, d32)
+    # raw stem output stored as bf16 (x_bf16 = 1, the bf16 trunk's default): the kernels fed the bf16 tensor equal the fp32
+    # kernels fed the same values widened to fp32, bit for bit
+    raw16 = raw.bfloat16(); raw16f = raw16.float()
+    y16b = torch.empty_like(y16); i16b = torch.empty_like(i32)
+    L.call("edrl_maxpool3x3s2_bn_fwd_f32", P(raw16f), P(fc), P(y32), P(i32), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_fwd_mx", P(raw16), 1, P(fc), P(y16b), 1, P(i16b), N, H, W, C)
+    assert torch.equal(y16b, y32.bfloat16()) and torch.equal(i16b, i32)
+    ws32.zero_(); ws16.zero_()
+    L.call("edrl_maxpool3x3s2_bn_bwd_reduce_f32", P(dy32), P(i32), P(raw16f), P(fc), P(ws32), nb, N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dy16), 1, P(i32), P(raw16), 1, P(fc), P(ws16), nb, N, H, W, C)
+    assert torch.equal(ws16[:chunks * 3 * C].view(chunks, 3, C)[:, :2], ws32[:chunks * 3 * C].view(chunks, 3, C)[:, :2])
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_f32", P(dy32), P(i32), P(raw16f), P(fc), P(bc), P(d32), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw16), 1, P(fc), P(bc), P(d16), N, H, W, C)
+    assert torch.equal(d16, d32)
+    assert L.lib().fn["edrl_maxpool3x3s2_bn_fwd_mx"](P(raw16), 1, P(fc), P(y32), 0, P(i16b), N, H, W, C, L.stream()) == -22, \
+        "a bf16 raw tensor needs a bf16 pooled tensor"
+    L.call("edrl_maxpool3x3s2_bn_fwd_f32", P(raw), P(fc), P(y32), P(i32), N, H, W, C)      # (restored for the torch check below)
     # and the fp32 pair itself against torch: max-pool of relu(x*scale + shift2), gradient routed to the first arg-max
     act = torch.relu(torch.addcmul(fc[4], raw, fc[2])).permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
     ref = F.max_pool2d(act, 3, 2, 1)
     check("fused stem fwd vs torch", y32.permute(0, 3, 1, 2).cpu(), ref, 1e-6)
+
+
+@pytest.mark.parametrize("in_ch,H,W", [(1, 64, 48), (3, 32, 64), (1, 33, 47)])
+def test_stem_conv_obf16_matches_fp32_kernel(edrl, dev, in_ch, H, W):
+    """The bf16 trunk's stem conv (edrl_conv2d_nhwc_fwd_stats_f32_obf16: fp32 image, fp32 MFMA, bf16 store, BatchNorm partials from
+    the accumulators): its output is the fp32 stem conv's output rounded to bf16 ONCE, bit for bit (same tiles, same accumulation
+    order), and the finalised statistics are those of the UNROUNDED fp64 conv (1e-4 / 1e-4 relative) -- space-to-depth geometry
+    (even sizes; 1 and 3 image channels) and the plain 7x7/s2 fallback (odd sizes), ragged last tile."""
+    ops = edrl.ops
+    L = edrl._lib
+    N, Co = 3, 64
+    g = torch.Generator().manual_seed(17)
+    cp = 4
+    x = torch.zeros(N, H, W, cp)
+    x[..., :in_ch] = torch.rand(N, H, W, in_ch, generator=g)
+    w = torch.zeros(Co, 7, 7, cp)
+    w[..., :in_ch] = 0.1 * torch.randn(Co, 7, 7, in_ch, generator=g)
+    xh, wh = x.to(dev), w.to(dev)
+    y32, _, _ = ops.stem_conv_fwd(xh, wh)
+    y16, part, chunks, _, folded = ops.stem_conv_fwd_obf16(xh, wh)
+    assert folded == (H % 2 == 0 and W % 2 == 0)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())
+    M = y16.numel() // Co
+    outs = [torch.empty(Co, device=dev) for _ in range(4)]
+    gbytes = L.query("edrl_bn_finalize_group_ws_bytes", chunks, Co)
+    gws = torch.empty(max(gbytes // 8, 1), device=dev, dtype=torch.float64)
+    L.call("edrl_bn_finalize_partials_f32", L.ptr(part), chunks, 128, M, Co, None, None, None, None, 0.1, 1e-5,
+           L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(outs[3]), L.ptr(gws), gbytes)
+    yd = F.conv2d(nchw(x.double()), w.double().permute(0, 3, 1, 2), stride=2, padding=3).permute(0, 2, 3, 1).reshape(-1, Co)
+    check("stem obf16 mean", outs[0].cpu(), yd.mean(0), 1e-4)
+    check("stem obf16 rstd", outs[1].cpu(), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-4)
 
 
 def test_bn_draw_bf16_kernel(edrl, dev):
