@@ -72,6 +72,12 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
                                size_t workspace_bytes, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
                                int Co, int KH, int KW, int stride, int pad, long ld_dy, long ld_x,
                                int accumulate, hipStream_t stream);
+/* The same weight gradient with dy stored as bf16 (dense [N,Ho,Wo,Co], widened exactly on load) and x fp32: the stem of the bf16
+ * trunk.  Co <= 64, Co % 4 == 0, Ci % 4 == 0; workspace as edrl_conv2d_nhwc_wgrad_workspace_bytes. */
+int edrl_conv2d_nhwc_wgrad_f32_dybf16_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW);  /* 1 / 0 */
+int edrl_conv2d_nhwc_wgrad_f32_dybf16(const void* dy_bf16, const float* x, float* dw, float* workspace, size_t workspace_bytes,
+                                      int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                      int accumulate, hipStream_t stream);
 
 /* ---- Convolutions with the neighbouring BatchNorm passes folded in (encoder slots behind fusion_net.py:884-885; SURVEY.md
  * §8a rows E1-E3: conv -> BatchNorm2d(train) -> ReLU chains).  Dense NHWC fp32 tensors, 16-byte aligned.  Coefficient arrays:
@@ -191,14 +197,14 @@ int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx
                                        const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t stream);
 /* The same three with the pooled tensor (y) / its gradient (dy) stored as bf16 when y_bf16 / dy_bf16 is 1, and the raw stem conv
  * output x stored as bf16 when x_bf16 is 1 (needs the other flag too): the stem of the bf16 trunk (C2/C4; the statistics and
- * d_raw, which feeds the fp32 stem weight gradient, stay fp32). */
+ * d_raw is fp32, or bf16 with d_bf16 = 1 (needs x_bf16; consumed by edrl_conv2d_nhwc_wgrad_f32_dybf16)). */
 int edrl_maxpool3x3s2_bn_fwd_mx(const void* x, int x_bf16, const float* fcoef, void* y, int y_bf16, unsigned char* idx, int N, int H,
                                 int W, int C, hipStream_t stream);
 int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsigned char* idx, const void* x, int x_bf16,
                                        const float* fcoef, float* part, size_t part_bytes, int N, int H, int W, int C,
                                        hipStream_t stream);
 int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const void* x, int x_bf16,
-                                      const float* fcoef, const float* bcoef, float* d_raw, int N, int H, int W, int C,
+                                      const float* fcoef, const float* bcoef, void* d_raw, int d_bf16, int N, int H, int W, int C,
                                       hipStream_t stream);
 
 /* bf16 counterparts of the fused-BatchNorm entry points (conv_bf16.hip / bn_pool.hip): bf16 tensors, fp32 coefficient arrays

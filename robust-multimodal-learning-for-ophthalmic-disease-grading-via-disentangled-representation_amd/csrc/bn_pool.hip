@@ -775,11 +775,11 @@ __device__ __forceinline__ f32x4 maxpool_bn_gather_g(const TY* __restrict__ dy, 
 }
 
 #define MPB_ROWS_PER_BLOCK 512     // MODE 1: pixels per workgroup
-template <int MODE, typename TY, typename TX = float>
+template <int MODE, typename TY, typename TX = float, typename TD = float>
 __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const TY* __restrict__ dy, const unsigned char* __restrict__ idx,
                                                              const TX* __restrict__ x, const float* __restrict__ fcoef,
                                                              const float* __restrict__ bcoef, float* __restrict__ part,
-                                                             float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+                                                             TD* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
   // Both modes: grid (row chunks, C/256 column blocks); a workgroup walks a CONTIGUOUS pixel range with CG = min(C/4, 64) column
   // lanes x RL = 256/CG pixel lanes; the (n, h, w) of a lane's pixel is decoded once (the only 64-bit division) and then advanced
   // by RL pixels per step with carries -- no per-element division.
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const TY* __restric
       const f32x4 xr = ld4<TX>(x + r * C + c);
       const f32x4 g = maxpool_bn_gather_g<TY>(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo);
       if (MODE == 1) {
-        *reinterpret_cast<f32x4*>(dx + r * C + c) = edrl_bn_bwd_dx2(g, xr, p0, p1, p2);
+        st4<TD>(dx + r * C + c, edrl_bn_bwd_dx2(g, xr, p0, p1, p2));
       } else {
         s0 += g;
         s1 += g * ((xr - p0) * p1);
@@ -1548,26 +1548,30 @@ int edrl_maxpool3x3s2_bn_bwd_reduce_f32(const float* dy, const unsigned char* id
   return edrl_maxpool3x3s2_bn_bwd_reduce_mx(dy, 0, idx, x, 0, fcoef, part, part_bytes, N, H, W, C, st);
 }
 int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigned char* idx, const void* x, int x_bf16,
-                                      const float* fcoef, const float* bcoef, float* d_raw, int N, int H, int W, int C,
+                                      const float* fcoef, const float* bcoef, void* d_raw, int d_bf16, int N, int H, int W, int C,
                                       hipStream_t st) {
-  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !bcoef || !d_raw || (x_bf16 && !dy_bf16)) return EDRL_EINVAL;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || !bcoef || !d_raw || (x_bf16 && !dy_bf16) || (d_bf16 && !x_bf16))
+    return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(edrl_cdiv((long)N * H * W, MPB_ROWS_PER_BLOCK), edrl_cdiv(C, 256));
-  if (x_bf16)
+  if (d_bf16)
+    hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16, __bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x,
+                       fcoef, bcoef, (float*)nullptr, (__bf16*)d_raw, N, H, W, C, Ho, Wo);
+  else if (x_bf16)
     hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x,
-                       fcoef, bcoef, (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
+                       fcoef, bcoef, (float*)nullptr, (float*)d_raw, N, H, W, C, Ho, Wo);
   else if (dy_bf16)
     hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const float*)x, fcoef, bcoef,
-                       (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
+                       (float*)nullptr, (float*)d_raw, N, H, W, C, Ho, Wo);
   else
     hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, float>), grid, dim3(256), 0, st, (const float*)dy, idx, (const float*)x, fcoef, bcoef,
-                       (float*)nullptr, d_raw, N, H, W, C, Ho, Wo);
+                       (float*)nullptr, (float*)d_raw, N, H, W, C, Ho, Wo);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
 int edrl_maxpool3x3s2_bn_bwd_apply_f32(const float* dy, const unsigned char* idx, const float* x, const float* fcoef,
                                        const float* bcoef, float* d_raw, int N, int H, int W, int C, hipStream_t st) {
-  return edrl_maxpool3x3s2_bn_bwd_apply_mx(dy, 0, idx, x, 0, fcoef, bcoef, d_raw, N, H, W, C, st);
+  return edrl_maxpool3x3s2_bn_bwd_apply_mx(dy, 0, idx, x, 0, fcoef, bcoef, d_raw, 0, N, H, W, C, st);
 }
 
 int edrl_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st) {

@@ -1149,10 +1149,14 @@ struct WgradFuse {
 };
 // MASKX (XT 1): the conv has padding taps, which must read as exactly 0 after the transform (3x3); a 1x1 / pad-0 layer's only
 // invalid X rows are those past the end of the tensor, and they meet dY rows that DYT has already zeroed.
-template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true>
+// DY16 (FASTLD, no transforms): `dy` is a bf16 tensor, widened exactly on load (the stem of the bf16 trunk: its d_raw is stored as bf16).
+template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true,
+          bool DY16 = false>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g, WgradFuse F) {
   static_assert((DYT == 0 && XT == 0) || FASTLD, "operand transforms ride on the buffer-descriptor path");
+  static_assert(!DY16 || (FASTLD && DYT == 0), "bf16 dY: plain buffer-load path only");
+  constexpr unsigned EBY = DY16 ? 2u : 4u;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_LD = (BM * BKT / 4) / 256, B_LD = (BN * BKT / 4) / 256;
@@ -1226,10 +1230,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const long p_lo = (long)t_begin * BKT;
     long p_hi = (long)t_end * BKT; if (p_hi > g.P) p_hi = g.P;
     long rows = p_hi - p_lo; if (rows < 1) rows = 1;
-    const unsigned ld4y = (unsigned)(g.ld_dy * 4), ld4x = (unsigned)(g.ld_x * 4);
-    const unsigned dy_bytes = (unsigned)((rows - 1) * ld4y + (unsigned)g.Co * 4u);
-    rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p_lo * g.ld_dy), 0, (int)dy_bytes, 0x00020000);
-    dy_last = dy_bytes - 16u;
+    const unsigned ld4y = (unsigned)g.ld_dy * EBY, ld4x = (unsigned)(g.ld_x * 4);
+    const unsigned dy_bytes = (unsigned)((rows - 1) * ld4y + (unsigned)g.Co * EBY);
+    rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)dy + p_lo * g.ld_dy * (long)EBY), 0, (int)dy_bytes, 0x00020000);
+    dy_last = dy_bytes - 4u * EBY;
     if constexpr (DYT == 2) {
       rs_dy2 = __builtin_amdgcn_make_buffer_rsrc((void*)(F.dy2 + p_lo * g.ld_dy), 0, (int)dy_bytes, 0x00020000);
       const int co = co0 + ac4 * 4;
@@ -1247,7 +1251,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const int co = co0 + ac4 * 4;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      a_off[i] = co < g.Co ? (unsigned)((tid + 256 * i) / AC4) * ld4y + (unsigned)co * 4u : OOB;
+      a_off[i] = co < g.Co ? (unsigned)((tid + 256 * i) / AC4) * ld4y + (unsigned)co * EBY : OOB;
     a_step = BKT * ld4y;
     const int a16 = BKT / g.OW, b16 = BKT - a16 * g.OW;
     c_step = (unsigned)(b16 * g.stride + a16 * g.stride * g.SW) * ld4x;
@@ -1290,7 +1294,12 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   auto load_tile_fast = [&]() {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_off[i], 0, 0));
+      if constexpr (DY16) {
+        const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)a_off[i], 0, 0));
+        const u32x4 wv = {r[0] << 16, r[0] & 0xffff0000u, r[1] << 16, r[1] & 0xffff0000u};
+        a_st[i] = __builtin_bit_cast(f32x4, wv);
+      } else
+        a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)a_off[i], 0, 0));
       if constexpr (DYT == 2) {
         a2_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy2, (int)a_off[i], 0, 0));
         a_ok[i] = a_off[i] <= dy_last;       // the hardware range check, restated: rows past the split / channels >= Co
@@ -1520,11 +1529,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #define WG_BK 16
 #define WG_OCC 4
 #define WG_OCC_FUSED 3
-template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true>
+template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true, bool DY16 = false>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st, const WgradFuse* fuse = nullptr) {
   const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (XT ? WG_OCC_FUSED : WG_OCC), FASTLD, DYT, XT, MASKX>;
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (XT ? WG_OCC_FUSED : WG_OCC), FASTLD, DYT, XT, MASKX, DY16>;
   WgradFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   static bool attr_set = false;
@@ -1781,6 +1790,43 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
                                int accumulate, hipStream_t st) {
   return wgrad_impl(dy, x, dw, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, ld_dy, ld_x,
                     accumulate, nullptr, st);
+}
+
+// The same weight gradient with dy stored as bf16 (dense [N,Ho,Wo,Co]) and x fp32: the stem of the bf16 trunk, whose d_raw comes out
+// of edrl_maxpool3x3s2_bn_bwd_apply_mx as bf16.  Co <= 64, Co % 4 == 0, Ci % 4 == 0, buffer-load path geometry (-22 otherwise);
+// workspace as edrl_conv2d_nhwc_wgrad_workspace_bytes.
+// 1 when the geometry is served by edrl_conv2d_nhwc_wgrad_f32_dybf16 (dense tensors), 0 otherwise (widen dy and use the fp32 entry).
+int edrl_conv2d_nhwc_wgrad_f32_dybf16_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || Co > 64 || KH <= 0 || KW <= 0) return 0;
+  const long P = (long)N * Ho * Wo;
+  if (P > 0x7fffffffL) return 0;
+  int bm, bn, splits, tps;
+  wgrad_plan(P, Co, KH * KW * Ci, KH * KW, &bm, &bn, &splits, &tps);
+  return wgrad_fast_ok((const float*)nullptr, (const float*)nullptr, Hi, Wi, Ci, Ho, Wo, Co, Co, Ci, tps) ? 1 : 0;
+}
+int edrl_conv2d_nhwc_wgrad_f32_dybf16(const void* dy_bf16, const float* x, float* dw, float* workspace, size_t workspace_bytes,
+                                      int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
+                                      int accumulate, hipStream_t st) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || Co > 64 || stride <= 0 || pad < 0 || !dy_bf16)
+    return EDRL_EINVAL;
+  WgradGeom g;
+  g.P = (long)N * Ho * Wo;
+  if (g.P > 0x7fffffffL) return EDRL_EINVAL;
+  g.OH = Ho; g.OW = Wo; g.Co = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Ci;
+  g.ld_dy = Co; g.ld_x = Ci;
+  int bm, bn, splits;
+  wgrad_plan(g.P, Co, g.Ktot, KH * KW, &bm, &bn, &splits, &g.tiles_per_split);
+  if (workspace_bytes < (size_t)splits * Co * g.Ktot * sizeof(float) || workspace == nullptr) return EDRL_ENOSPC;
+  if (((uintptr_t)dy_bf16 & 7) || !wgrad_fast_ok((const float*)nullptr, x, Hi, Wi, Ci, Ho, Wo, Co, Co, Ci, g.tiles_per_split))
+    return EDRL_EINVAL;
+  const int rc = bn == 64 ? launch_wgrad<64, 64, true, true, 0, 0, true, true>((const float*)dy_bf16, x, workspace, g, splits, st)
+                          : launch_wgrad<64, 128, true, true, 0, 0, true, true>((const float*)dy_bf16, x, workspace, g, splits, st);
+  if (rc) return rc;
+  const long n = (long)Co * g.Ktot;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n, splits, accumulate);
+  EDRL_LAUNCH_CHECK();
+  return 0;
 }
 
 // Weight gradient with the BatchNorm passes on either side folded into the operand loads (dense NHWC tensors):

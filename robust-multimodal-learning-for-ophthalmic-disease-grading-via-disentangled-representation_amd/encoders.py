@@ -361,9 +361,10 @@ class _KBF16:
                                  P(idx), P(raw), r16, P(fc), P(ws), nbytes, N, H, W, C)
             bc, dg, db = _bcoef_from_partials(ws, (M + 1023) // 1024, 3, M, p["bn1.weight"], fc)
             grads["bn1.weight"], grads["bn1.bias"] = dg, db
-            draw = torch.empty(raw.shape, device=raw.device, dtype=torch.float32)    # fp32 gradient for the fp32 stem weight gradient
-            ops.call_timed_bytes("maxpool_bn_bwd", M * C * (4.0 + relt) + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dcur), 1,
-                                 P(idx), P(raw), r16, P(fc), P(bc), P(draw), N, H, W, C)
+            # d_raw in the raw tensor's storage type: the stem weight gradient (fp32 image operand) widens a bf16 d_raw on load
+            draw = torch.empty(raw.shape, device=raw.device, dtype=raw.dtype)
+            ops.call_timed_bytes("maxpool_bn_bwd", M * C * 2.0 * relt + dcur.numel() * 3.0, "edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dcur), 1,
+                                 P(idx), P(raw), r16, P(fc), P(bc), P(draw), r16, N, H, W, C)
             grads["conv1.weight"] = ops.stem_conv_wgrad(draw, x, tuple(p["conv1.weight"].shape), folded)
             return None
         x, folded, raw, a0_shape, m0, r0, k0, idx = stem

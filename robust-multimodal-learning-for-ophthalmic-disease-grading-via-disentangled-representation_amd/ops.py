@@ -237,6 +237,7 @@ def stem_conv_fwd_obf16(x, w):
 
 
 def stem_conv_wgrad(dy, x_saved, w_shape, folded):
+    """dy fp32, or bf16 (the bf16 trunk's stem: fp32 x, dy widened on load)."""
     if not folded:
         return conv2d_wgrad(dy, x_saved, tuple(w_shape), 2, 3)
     Co, _, _, C = w_shape
@@ -280,6 +281,13 @@ def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=False, al
         accumulate = False
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
     ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+    if dy.dtype == torch.bfloat16:      # fp32 x, bf16 dy (widened exactly on load): the bf16 trunk's stem
+        if L.query("edrl_conv2d_nhwc_wgrad_f32_dybf16_ok", N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW):
+            _launch_timed("conv_wgrad", alg_flops or 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_f32_dybf16", P(dy),
+                          P(x), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 1 if accumulate else 0,
+                          nbytes=2.0 * dy.numel() + 4.0 * (x.numel() + out.numel()))
+            return out
+        dy = to_f32(dy)                 # geometry outside the buffer-load path: the same values through the fp32 kernel
     _launch_timed("conv_wgrad", alg_flops or 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_f32", P(dy), P(x),
                   P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, 1 if accumulate else 0,
                   nbytes=4.0 * (dy.numel() + x.numel() + out.numel()))

@@ -206,7 +206,7 @@ def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
     bc[2] = 0.01 * torch.randn(C, generator=g).to(dev); bc[3] = fc[0]
     d32 = torch.empty_like(raw); d16 = torch.empty_like(raw)
     L.call("edrl_maxpool3x3s2_bn_bwd_apply_f32", P(dy32), P(i32), P(raw), P(fc), P(bc), P(d32), N, H, W, C)
-    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw), 0, P(fc), P(bc), P(d16), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw), 0, P(fc), P(bc), P(d16), 0, N, H, W, C)
     assert torch.equal(d16, d32)
     # raw stem output stored as bf16 (x_bf16 = 1, the bf16 trunk's default): the kernels fed the bf16 tensor equal the fp32
     # kernels fed the same values widened to fp32, bit for bit
@@ -220,8 +220,11 @@ def test_fused_stem_mx_matches_fp32_kernels(edrl, dev):
     L.call("edrl_maxpool3x3s2_bn_bwd_reduce_mx", P(dy16), 1, P(i32), P(raw16), 1, P(fc), P(ws16), nb, N, H, W, C)
     assert torch.equal(ws16[:chunks * 3 * C].view(chunks, 3, C)[:, :2], ws32[:chunks * 3 * C].view(chunks, 3, C)[:, :2])
     L.call("edrl_maxpool3x3s2_bn_bwd_apply_f32", P(dy32), P(i32), P(raw16f), P(fc), P(bc), P(d32), N, H, W, C)
-    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw16), 1, P(fc), P(bc), P(d16), N, H, W, C)
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw16), 1, P(fc), P(bc), P(d16), 0, N, H, W, C)
     assert torch.equal(d16, d32)
+    dh = torch.empty(N, H, W, C, device=dev, dtype=torch.bfloat16)          # d_raw stored as bf16: the same values rounded once
+    L.call("edrl_maxpool3x3s2_bn_bwd_apply_mx", P(dy16), 1, P(i32), P(raw16), 1, P(fc), P(bc), P(dh), 1, N, H, W, C)
+    assert torch.equal(dh, d32.bfloat16())
     assert L.lib().fn["edrl_maxpool3x3s2_bn_fwd_mx"](P(raw16), 1, P(fc), P(y32), 0, P(i16b), N, H, W, C, L.stream()) == -22, \
         "a bf16 raw tensor needs a bf16 pooled tensor"
     L.call("edrl_maxpool3x3s2_bn_fwd_f32", P(raw), P(fc), P(y32), P(i32), N, H, W, C)      # (restored for the torch check below)
@@ -260,6 +263,12 @@ def test_stem_conv_obf16_matches_fp32_kernel(edrl, dev, in_ch, H, W):
     yd = F.conv2d(nchw(x.double()), w.double().permute(0, 3, 1, 2), stride=2, padding=3).permute(0, 2, 3, 1).reshape(-1, Co)
     check("stem obf16 mean", outs[0].cpu(), yd.mean(0), 1e-4)
     check("stem obf16 rstd", outs[1].cpu(), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-4)
+    # weight gradient with a bf16 d_raw (edrl_conv2d_nhwc_wgrad_f32_dybf16) == the fp32 kernel fed the widened values, bit for bit
+    _, xk, _ = ops.stem_conv_fwd(xh, wh)
+    dy16 = torch.randn(y16.shape, generator=g).bfloat16().to(dev)
+    dw16 = ops.stem_conv_wgrad(dy16, xk, tuple(w.shape), folded)
+    dw32 = ops.stem_conv_wgrad(dy16.float(), xk, tuple(w.shape), folded)
+    assert torch.equal(dw16, dw32)
 
 
 def test_bn_draw_bf16_kernel(edrl, dev):
