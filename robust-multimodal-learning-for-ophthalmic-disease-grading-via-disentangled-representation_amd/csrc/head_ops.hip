@@ -105,6 +105,84 @@ __global__ __launch_bounds__(256) void l2norm_axis1_bwd_kernel(const float* __re
   }
 }
 
+// Few columns, long axis (the proxy tensors: A*D = 512 columns, L = all tokens of the batch): one thread per column walks L serially
+// and 2 workgroups run for ~0.3 ms.  Cooperative forms: a workgroup owns 16 columns, its 16 row lanes split L (row lane r takes
+// l = r, r+16, ...: fixed order), partial sums combined in lane order through LDS (deterministic), second sweep by the same lanes.
+#define CO_DL 16
+#define CO_RL 16
+template <int NS>
+__device__ __forceinline__ void co_reduce(float (&s)[NS], float* sh, int rl, int dl) {
+#pragma unroll
+  for (int q = 0; q < NS; ++q) sh[(q * CO_RL + rl) * CO_DL + dl] = s[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    float t = 0.f;
+    for (int r = 0; r < CO_RL; ++r) t += sh[(q * CO_RL + r) * CO_DL + dl];
+    s[q] = t;
+  }
+}
+__global__ __launch_bounds__(256) void l2norm_axis1_fwd_co_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  float* __restrict__ inv, long A, int L, int D, float eps) {
+  __shared__ float sh[CO_RL * CO_DL];
+  const int dl = threadIdx.x % CO_DL, rl = threadIdx.x / CO_DL;
+  const long i = (long)blockIdx.x * CO_DL + dl;
+  const bool ok = i < A * D;
+  const long a = ok ? i / D : 0;
+  const int d = ok ? (int)(i - a * D) : 0;
+  const float* px = x + a * L * D + d;
+  float s[1] = {0.f};
+  if (ok)
+    for (int l = rl; l < L; l += CO_RL) { const float v = px[(long)l * D]; s[0] += v * v; }
+  co_reduce<1>(s, sh, rl, dl);
+  if (!ok) return;
+  const float nrm = sqrtf(s[0]);
+  const float iv = 1.f / fmaxf(nrm, eps);
+  if (rl == 0) inv[i] = nrm > eps ? iv : -iv;
+  float* py = y + a * L * D + d;
+  for (int l = rl; l < L; l += CO_RL) py[(long)l * D] = px[(long)l * D] * iv;
+}
+__global__ __launch_bounds__(256) void l2norm_axis1_bwd_co_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ inv, float* __restrict__ dx, long A, int L,
+                                                                  int D) {
+  __shared__ float sh[CO_RL * CO_DL];
+  const int dl = threadIdx.x % CO_DL, rl = threadIdx.x / CO_DL;
+  const long i = (long)blockIdx.x * CO_DL + dl;
+  const bool ok = i < A * D;
+  const long a = ok ? i / D : 0;
+  const int d = ok ? (int)(i - a * D) : 0;
+  const long base = a * L * D + d;
+  const float ivs = ok ? inv[i] : 0.f;
+  const float iv = fabsf(ivs);
+  float s[1] = {0.f};
+  if (ok && ivs > 0.f)
+    for (int l = rl; l < L; l += CO_RL) s[0] += dy[base + (long)l * D] * y[base + (long)l * D];
+  co_reduce<1>(s, sh, rl, dl);
+  if (!ok) return;
+  for (int l = rl; l < L; l += CO_RL) dx[base + (long)l * D] = iv * (dy[base + (long)l * D] - y[base + (long)l * D] * s[0]);
+}
+__global__ __launch_bounds__(256) void affine_bcast_bwd_co_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                                  float* __restrict__ du, float* __restrict__ dv, long A, int L, int D) {
+  __shared__ float sh[2 * CO_RL * CO_DL];
+  const int dl = threadIdx.x % CO_DL, rl = threadIdx.x / CO_DL;
+  const long i = (long)blockIdx.x * CO_DL + dl;
+  const bool ok = i < A * D;
+  const long a = ok ? i / D : 0;
+  const int d = ok ? (int)(i - a * D) : 0;
+  const long base = a * L * D + d;
+  float s[2] = {0.f, 0.f};
+  if (ok)
+    for (int l = rl; l < L; l += CO_RL) {
+      const float g = dout[base + (long)l * D];
+      s[0] += g;
+      s[1] += g * w[base + (long)l * D];
+    }
+  co_reduce<2>(s, sh, rl, dl);
+  if (ok && rl == 0) { du[i] = s[0]; dv[i] = s[1]; }
+}
+// cooperative form when the column count leaves most of the chip idle and the serial walk is long
+static inline bool co_shape(long A, int L, int D) { return A * D <= 256L * 128 && L >= 64; }
+
 // out[a][l][d] = u[a][d] + v[a][d] * w[a][l][d]
 __global__ __launch_bounds__(256) void affine_bcast_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                                const float* __restrict__ w, float* __restrict__ out,
@@ -790,14 +868,20 @@ int edrl_scalar_mix_f32(const float* const* in, const float* w, int n, float* ou
 int edrl_l2norm_axis1_fwd_f32(const float* x, float* y, float* inv, long A, int L, int D, float eps,
                               hipStream_t st) {
   if (A <= 0 || L <= 0 || D <= 0) return EDRL_EINVAL;
-  hipLaunchKernelGGL(l2norm_axis1_fwd_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, x, y, inv, A, L, D, eps);
+  if (co_shape(A, L, D))
+    hipLaunchKernelGGL(l2norm_axis1_fwd_co_kernel, dim3((unsigned)edrl_cdiv(A * D, CO_DL)), dim3(256), 0, st, x, y, inv, A, L, D, eps);
+  else
+    hipLaunchKernelGGL(l2norm_axis1_fwd_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, x, y, inv, A, L, D, eps);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
 int edrl_l2norm_axis1_bwd_f32(const float* dy, const float* y, const float* inv, float* dx, long A, int L, int D,
                               hipStream_t st) {
   if (A <= 0 || L <= 0 || D <= 0) return EDRL_EINVAL;
-  hipLaunchKernelGGL(l2norm_axis1_bwd_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, dy, y, inv, dx, A, L, D);
+  if (co_shape(A, L, D))
+    hipLaunchKernelGGL(l2norm_axis1_bwd_co_kernel, dim3((unsigned)edrl_cdiv(A * D, CO_DL)), dim3(256), 0, st, dy, y, inv, dx, A, L, D);
+  else
+    hipLaunchKernelGGL(l2norm_axis1_bwd_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, dy, y, inv, dx, A, L, D);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
@@ -812,7 +896,10 @@ int edrl_affine_bcast_fwd_f32(const float* u, const float* v, const float* w, fl
 int edrl_affine_bcast_bwd_f32(const float* dout, const float* w, float* du, float* dv, long A, int L, int D,
                               hipStream_t st) {
   if (A <= 0 || L <= 0 || D <= 0) return EDRL_EINVAL;
-  hipLaunchKernelGGL(affine_bcast_bwd_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, dout, w, du, dv, A, L, D);
+  if (co_shape(A, L, D))
+    hipLaunchKernelGGL(affine_bcast_bwd_co_kernel, dim3((unsigned)edrl_cdiv(A * D, CO_DL)), dim3(256), 0, st, dout, w, du, dv, A, L, D);
+  else
+    hipLaunchKernelGGL(affine_bcast_bwd_kernel, dim3(ew_grid(A * D)), dim3(256), 0, st, dout, w, du, dv, A, L, D);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

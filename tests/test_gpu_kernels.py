@@ -203,6 +203,20 @@ def test_head_reductions(edrl, dev):
     (yg * gy.to(dev)).sum().backward()
     check("l2norm_fwd", yg.cpu(), y, 1e-6)
     check("l2norm_bwd", xg.grad.cpu(), xd.grad, 1e-5)
+    # few columns, long axis (the proxy tensors): the cooperative kernels (16 row lanes per column); ragged last workgroup and an
+    # all-zero column (clamped denominator: zero output, gradient dy / eps as torch's)
+    xl = torch.randn(1, 700, 520, generator=g)
+    xl[:, :, 7] = 0.0
+    xld = xl.double().requires_grad_(True)
+    yl = F.normalize(xld, dim=1)
+    gyl = torch.randn(yl.shape, generator=g)
+    (yl * gyl.double()).sum().backward()
+    xlg = xl.to(dev).requires_grad_(True)
+    ylg = ops.l2norm_axis1(xlg)
+    (ylg * gyl.to(dev)).sum().backward()
+    check("l2norm_fwd long axis", ylg.cpu(), yl, 1e-6)
+    check("l2norm_bwd long axis", xlg.grad.cpu(), xld.grad, 1e-5)
+    assert float(ylg[:, :, 7].abs().max()) == 0.0
     xg2 = x.to(dev).requires_grad_(True)
     m = ops.mean_axis1(xg2)
     m.backward(gy[:, 0].to(dev).contiguous())
