@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_h_kernel(const float* __res
 }
 
 static void wgrad_plan_h(long P, int Co, int Ktot, int* splits, int* tiles_per_split) {
-  const long tiles = (long)edrl_cdiv(Co, 128) * edrl_cdiv(Ktot, 128);
+  const long tiles = (long)edrl_cdiv(Co, 128) * edrl_cdiv(Ktot, 128);      // (Co <= 64 runs 64-row tiles: the same count)
   const long ptiles = (P + WBK - 1) / WBK;
   // 768 workgroups are resident (256 CUs x 3): aim just under a whole number of rounds (see conv_gemm.hip wgrad_plan)
   static const long target = []() { const char* e = getenv("EDRL_WGRAD_TARGET_BF16"); return e ? atol(e) : 1536L; }();
@@ -955,6 +955,22 @@ static int wgrad_bf16_impl(const void* dy, const void* x, float* dw, float* work
   if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
   constexpr int BM = 128, BN = 128;
   const size_t lds = (size_t)2 * WBK * ((BM + 32) + (BN + 32)) * sizeof(__bf16);
+  // Co <= 64 (the 3x3 layers of the first residual stage): 64-row tiles -- half of a 128-row tile's MFMAs would multiply zeros
+  static const bool bm64_env = []() { const char* e = getenv("EDRL_BF16_WGRAD_BM64"); return !(e && e[0] == '0'); }();
+  if (!fuse && Co <= 64 && bm64_env && wgrad_fast_ok_h(Hi, Wi, Ci, Ho, Wo, Co, g.tiles_per_split)) {
+    const size_t lds64 = (size_t)2 * WBK * ((64 + 32) + (BN + 32)) * sizeof(__bf16);
+    g.tiles_x = edrl_cdiv(g.Ktot, BN); g.tiles_y = 1;
+    const long nb = (long)g.tiles_x * splits;
+    WgradFuseH F0;
+    memset(&F0, 0, sizeof(F0));
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64, BN, true>), dim3((unsigned)nb), dim3(256), lds64, st, (const __bf16*)dy,
+                       (const __bf16*)x, workspace, g, F0);
+    EDRL_LAUNCH_CHECK();
+    const long n64 = (long)Co * g.Ktot;
+    hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(n64, 1024)), dim3(256), 0, st, workspace, dw, n64, splits, accumulate);
+    EDRL_LAUNCH_CHECK();
+    return 0;
+  }
   static const bool fast_env = []() { const char* e = getenv("EDRL_WGRAD_FAST"); return !(e && e[0] == '0'); }();
   const bool fast_ok = wgrad_fast_ok_h(Hi, Wi, Ci, Ho, Wo, Co, g.tiles_per_split);
   const bool fast = fast_env && fast_ok;
