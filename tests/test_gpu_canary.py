@@ -117,3 +117,61 @@ def test_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, Co, k,
         care = pre.abs() > 1e-6 * pre.abs().max()
         err = ((dx2.t.double().cpu().permute(0, 3, 1, 2) - a64.grad * keep) * care).abs().max() / a64.grad.abs().max()
         assert err < 5e-5, err
+
+
+BF16_GEOMS = [  # N, H, W, Ci, Co, k, stride, pad : channel counts the 256x256 LDS-DMA cores accept (multiples of 256) at row counts
+    # from 12 (far below one tile) to 686 (two and a bit), ragged last tiles, padding taps, stride-2 parity classes (incl. one that
+    # no tap reaches), pixel counts that are not multiples of the weight gradient's 32-pixel unit
+    (2, 7, 5, 256, 256, 3, 1, 1), (3, 4, 4, 256, 512, 1, 2, 0), (1, 9, 7, 512, 256, 3, 2, 1), (3, 2, 2, 256, 256, 3, 1, 1),
+    (14, 7, 7, 256, 256, 1, 1, 0), (2, 6, 6, 512, 512, 1, 2, 0),
+    # the 128-row / 128x128 kernels' domain: narrow layers, channel counts that end inside a tile
+    (2, 9, 9, 64, 64, 3, 1, 1), (3, 7, 5, 64, 200, 1, 1, 0), (2, 8, 8, 96, 64, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", BF16_GEOMS)
+def test_bf16_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, Co, k, s, p, mode, monkeypatch):
+    """The same guard-band check for the bf16 launchers: forward (+ BatchNorm partials), data gradient (write / accumulate), weight
+    gradient incl. its split-K workspace -- once on the 128-row / 128x128 kernels (mode 0) and once with the 256x256 LDS-DMA cores
+    forced wherever the geometry allows (mode 2: conv_bf16_v3.hip, conv_wgrad_bf16_v3.hip; their DMA pieces for rows / taps outside
+    the tensors are out-of-range buffer offsets and must neither fault nor leak into the outputs)."""
+    ops, L = edrl.ops, edrl._lib
+    P = L.ptr
+    monkeypatch.setenv("EDRL_BF16_V3", mode)
+    monkeypatch.setenv("EDRL_BF16_WGRAD_V3", mode)
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + Co)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(N, H, W, Ci, generator=g).to(bf)
+    w = (torch.randn(Co, k, k, Ci, generator=g) * 0.1).to(bf)
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(bf)
+    xd, wd, dyd = x.to(dev), w.to(dev), dy.to(dev)
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    y64 = F.conv2d(x64, w64, stride=s, padding=p)
+    y64.backward(dy.double().permute(0, 3, 1, 2))
+    rel = lambda a, b: ((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    tol = 2.0 ** -8
+    if Ci % 32 == 0 and Co % 4 == 0:
+        chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
+        y, part = Guarded((N, Ho, Wo, Co), dev, bf), Guarded((chunks, 3, Co), dev)
+        L.call("edrl_conv2d_nhwc_fwd_bf16", P(xd), P(wd), P(y.t), P(part.t), part.t.numel() * 4, N, H, W, Ci, Ho, Wo, Co, k, k, s, p)
+        torch.cuda.synchronize(); y.check("bf16 conv fwd (y)"); part.check("bf16 conv fwd (partials)")
+        assert rel(y.t.permute(0, 3, 1, 2), y64.detach()) < tol
+    if Co % 32 == 0 and Ci % 4 == 0:
+        wt = ops.permute_weight_bf16(wd.float())
+        dx = Guarded((N, H, W, Ci), dev, bf)
+        dx.t.zero_()          # (a stride-2 class that no tap reaches is left as it is)
+        L.call("edrl_conv2d_nhwc_dgrad_bf16", P(dyd), P(wt), P(dx.t), N, H, W, Ci, Ho, Wo, Co, k, k, s, p, 0)
+        torch.cuda.synchronize(); dx.check("bf16 conv dgrad")
+        assert rel(dx.t.permute(0, 3, 1, 2), x64.grad) < tol
+        L.call("edrl_conv2d_nhwc_dgrad_bf16", P(dyd), P(wt), P(dx.t), N, H, W, Ci, Ho, Wo, Co, k, k, s, p, 2)
+        torch.cuda.synchronize(); dx.check("bf16 conv dgrad (accumulate)")
+        assert rel(dx.t.permute(0, 3, 1, 2), 2 * x64.grad) < 2 * tol
+    if Co % 8 == 0 and Ci % 8 == 0:
+        nbytes = L.query("edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes", N, Ho, Wo, Co, Ci, k, k)
+        dw, ws = Guarded((Co, k, k, Ci), dev), Guarded((nbytes // 4,), dev)
+        L.call("edrl_conv2d_nhwc_wgrad_bf16", P(dyd), P(xd), P(dw.t), P(ws.t), nbytes, N, H, W, Ci, Ho, Wo, Co, k, k, s, p, 0)
+        torch.cuda.synchronize(); dw.check("bf16 conv wgrad"); ws.check("bf16 conv wgrad (split-K workspace)")
+        assert rel(dw.t.permute(0, 3, 1, 2), w64.grad) < 2e-5
