@@ -844,6 +844,188 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const TY* __restric
   }
 }
 
+// ---- all-bf16 forms of the three fused stem kernels (raw tensor, pooled tensor / its gradient and d_raw stored as bf16: the bf16
+// trunk), 8 channels per thread: the 4-channel kernels above move 8 bytes per load at bf16 and run instruction-bound (2.3 TB/s);
+// with 16-byte accesses the instruction count per byte halves.  Same arithmetic per channel (results bit-identical to the 4-channel
+// kernels: tests/test_gpu_bf16.py).  C % 8 == 0.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void ld8h(const __bf16* p, f32x4& lo, f32x4& hi) {
+  const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { lo[e] = (float)v[e]; hi[e] = (float)v[4 + e]; }
+}
+__device__ __forceinline__ void st8h(__bf16* p, f32x4 lo, f32x4 hi) {
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+  *reinterpret_cast<bf16x8_t*>(p) = o;
+}
+__global__ __launch_bounds__(256) void maxpool_bn_fwd8_kernel(const __bf16* __restrict__ x, const float* __restrict__ fcoef,
+                                                              __bf16* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
+                                                              int W, int C, int Ho, int Wo) {
+  const int C8 = C >> 3;
+  const long total = (long)N * Ho * Wo * C8;
+  const long gs = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c8 = (int)(i % C8);
+  long t0 = i / C8;
+  int wo = (int)(t0 % Wo); t0 /= Wo;
+  int ho = (int)(t0 % Ho);
+  int n = (int)(t0 / Ho);
+  const int dc = (int)(gs % C8);
+  long t1 = gs / C8;
+  const int dwo = (int)(t1 % Wo); t1 /= Wo;
+  const int dho = (int)(t1 % Ho);
+  const int dn = (int)(t1 / Ho);
+  for (; i < total; i += gs) {
+    const int c = c8 * 8;
+    f32x4 sc[2], sh[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      sc[q] = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c + 4 * q);
+      sh[q] = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c + 4 * q);
+    }
+    f32x4 best[2] = {{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, {-INFINITY, -INFINITY, -INFINITY, -INFINITY}};
+    int bi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool any = false;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = ho * 2 - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = wo * 2 - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        f32x4 v[2];
+        ld8h(x + (((long)n * H + h) * W + w) * C + c, v[0], v[1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          v[q] = edrl_bn_relu2(v[q], sc[q], sh[q]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!any || v[q][e] > best[q][e] || v[q][e] != v[q][e]) { best[q][e] = v[q][e]; bi[4 * q + e] = kh * 3 + kw; }
+        }
+        any = true;
+      }
+    }
+    st8h(y + i * 8, best[0], best[1]);
+    uint2 pk;
+    pk.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+    pk.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+    *reinterpret_cast<uint2*>(idx + i * 8) = pk;
+    c8 += dc; wo += dwo; ho += dho; n += dn;
+    if (c8 >= C8) { c8 -= C8; ++wo; }
+    if (wo >= Wo) { wo -= Wo; ++ho; }
+    if (ho >= Ho) { ho -= Ho; ++n; }
+  }
+}
+// gradient gather of maxpool_bn_gather_g for 8 channels (two f32x4 halves)
+__device__ __forceinline__ void maxpool_bn_gather_g8(const __bf16* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                     const f32x4 (&xr)[2], const f32x4 (&sc)[2], const f32x4 (&sh)[2], int n, int h,
+                                                     int w, int c, int C, int Ho, int Wo, f32x4 (&s)[2]) {
+  s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0];
+  const int nh = (h & 1) ? 2 : 1, nw = (w & 1) ? 2 : 1;
+  const int ho0 = (h + 1) >> 1, wo0 = (w + 1) >> 1;
+  const int kh0 = (h & 1) ? 0 : 1, kw0 = (w & 1) ? 0 : 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    if (a >= nh) break;
+    const int ho = ho0 - a, kh = kh0 + 2 * a;
+    if (ho >= Ho) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (b >= nw) break;
+      const int wo = wo0 - b, kw = kw0 + 2 * b;
+      if (wo >= Wo) continue;
+      const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
+      const uint2 m = *reinterpret_cast<const uint2*>(idx + o);
+      f32x4 g[2];
+      ld8h(dy + o, g[0], g[1]);
+      const unsigned tap = (unsigned)(kh * 3 + kw);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (((m.x >> (8 * e)) & 0xff) == tap) s[0][e] += g[0][e];
+        if (((m.y >> (8 * e)) & 0xff) == tap) s[1][e] += g[1][e];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const f32x4 pre = edrl_bn_pre2(xr[q], sc[q], sh[q]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[q][e] = pre[e] > 0.f ? s[q][e] : 0.f;
+  }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd8_kernel(const __bf16* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                              const __bf16* __restrict__ x, const float* __restrict__ fcoef,
+                                                              const float* __restrict__ bcoef, float* __restrict__ part,
+                                                              __bf16* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+  // as maxpool_bn_bwd_kernel with CG = min(C/8, 32) column lanes of 8 channels
+  const int C8 = C >> 3;
+  const long M = (long)N * H * W;
+  const int CG = C8 < 32 ? C8 : 32;
+  const int RL = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, rl = tid / CG;
+  const int c = (blockIdx.y * 32 + cg) * 8;
+  const long row0 = (long)blockIdx.x * (MODE == 1 ? MPB_ROWS_PER_BLOCK : BN_ROWS_PER_CHUNK);
+  long row1 = row0 + (MODE == 1 ? MPB_ROWS_PER_BLOCK : BN_ROWS_PER_CHUNK);
+  if (row1 > M) row1 = M;
+  f32x4 s0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (c < C && rl < RL && row0 + rl < row1) {
+    f32x4 sc[2], sh[2], p0[2], p1[2], p2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      sc[q] = *reinterpret_cast<const f32x4*>(fcoef + 2 * (long)C + c + 4 * q);
+      sh[q] = *reinterpret_cast<const f32x4*>(fcoef + 4 * (long)C + c + 4 * q);
+      if (MODE == 1) {
+        p0[q] = *reinterpret_cast<const f32x4*>(bcoef + c + 4 * q);
+        p1[q] = *reinterpret_cast<const f32x4*>(bcoef + (long)C + c + 4 * q);
+        p2[q] = *reinterpret_cast<const f32x4*>(bcoef + 2 * (long)C + c + 4 * q);
+      } else {
+        p0[q] = *reinterpret_cast<const f32x4*>(fcoef + c + 4 * q);
+        p1[q] = *reinterpret_cast<const f32x4*>(fcoef + (long)C + c + 4 * q);
+        p2[q] = p0[q];
+      }
+    }
+    long r = row0 + rl;
+    int w = (int)(r % W);
+    const long t = r / W;
+    int h = (int)(t % H), n = (int)(t / H);
+    for (; r < row1; r += RL) {
+      f32x4 xr[2], g[2];
+      ld8h(x + r * C + c, xr[0], xr[1]);
+      maxpool_bn_gather_g8(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo, g);
+      if (MODE == 1) {
+        st8h(dx + r * C + c, edrl_bn_bwd_dx2(g[0], xr[0], p0[0], p1[0], p2[0]), edrl_bn_bwd_dx2(g[1], xr[1], p0[1], p1[1], p2[1]));
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { s0[q] += g[q]; s1[q] += g[q] * ((xr[q] - p0[q]) * p1[q]); }
+      }
+      w += RL;
+      while (w >= W) { w -= W; if (++h == H) { h = 0; ++n; } }
+    }
+  }
+  if (MODE == 1) return;
+  __shared__ float sh_[256 * 16];
+  float* my = sh_ + tid * 16;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { my[e] = s0[0][e]; my[4 + e] = s0[1][e]; my[8 + e] = s1[0][e]; my[12 + e] = s1[1][e]; }
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float a[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+    for (int q = 0; q < RL; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a[e] += sh_[(q * CG + cg) * 16 + e];
+    float* p = part + (long)blockIdx.x * 3 * C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { p[c + e] = a[e]; p[C + c + e] = a[8 + e]; }
+  }
+}
+
 // [N][C][H][W] -> [N][H][W][Cp] (channels >= C zero filled)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            int N, int C, int H, int W, int Cp) {
@@ -1504,7 +1686,12 @@ int edrl_maxpool3x3s2_bn_fwd_mx(const void* x, int x_bf16, const float* fcoef, v
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || (x_bf16 && !y_bf16)) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(ew_grid((long)N * Ho * Wo * (C / 4)));
-  if (x_bf16)
+  const char* v8e = getenv("EDRL_STEM_POOL_V8");      // (read per call: tests A/B the two forms in one process)
+  const bool v8_env = !(v8e && v8e[0] == '0');
+  if (x_bf16 && v8_env && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (((uintptr_t)idx) & 7) == 0)
+    hipLaunchKernelGGL(maxpool_bn_fwd8_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 8))), dim3(256), 0, st, (const __bf16*)x, fcoef,
+                       (__bf16*)y, idx, N, H, W, C, Ho, Wo);
+  else if (x_bf16)
     hipLaunchKernelGGL((maxpool_bn_fwd_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)x, fcoef, (__bf16*)y, idx, N, H, W,
                        C, Ho, Wo);
   else if (y_bf16)
@@ -1531,7 +1718,12 @@ int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsign
   if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256));
-  if (x_bf16)
+  const char* v8e = getenv("EDRL_STEM_POOL_V8");      // (read per call: tests A/B the two forms in one process)
+  const bool v8_env = !(v8e && v8e[0] == '0');
+  if (x_bf16 && v8_env && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && (((uintptr_t)idx) & 7) == 0)
+    hipLaunchKernelGGL((maxpool_bn_bwd8_kernel<0>), dim3(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256)), dim3(256), 0, st,
+                       (const __bf16*)dy, idx, (const __bf16*)x, fcoef, (const float*)nullptr, part, (__bf16*)nullptr, N, H, W, C, Ho, Wo);
+  else if (x_bf16)
     hipLaunchKernelGGL((maxpool_bn_bwd_kernel<0, __bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x,
                        fcoef, (const float*)nullptr, part, (float*)nullptr, N, H, W, C, Ho, Wo);
   else if (dy_bf16)
@@ -1554,7 +1746,12 @@ int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigne
     return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(edrl_cdiv((long)N * H * W, MPB_ROWS_PER_BLOCK), edrl_cdiv(C, 256));
-  if (d_bf16)
+  const char* v8e = getenv("EDRL_STEM_POOL_V8");      // (read per call: tests A/B the two forms in one process)
+  const bool v8_env = !(v8e && v8e[0] == '0');
+  if (d_bf16 && v8_env && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)d_raw) & 15) == 0 && (((uintptr_t)idx) & 7) == 0)
+    hipLaunchKernelGGL((maxpool_bn_bwd8_kernel<1>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x, fcoef, bcoef,
+                       (float*)nullptr, (__bf16*)d_raw, N, H, W, C, Ho, Wo);
+  else if (d_bf16)
     hipLaunchKernelGGL((maxpool_bn_bwd_kernel<1, __bf16, __bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x,
                        fcoef, bcoef, (float*)nullptr, (__bf16*)d_raw, N, H, W, C, Ho, Wo);
   else if (x_bf16)
