@@ -390,10 +390,11 @@ bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad) {
   if (!can) return false;
   if (mode == 2) return true;
   // Measured per layer against the 128-row kernel (scripts/v3_layer_bench.py, profiles/r03_v3_layers_bf16_2112img.txt): the forward
-  // wins from K = 1024 up (3x3 convs, 1x1 convs with >= 1024 input channels; K = 512 is a wash, K = 256 loses: one workgroup per
+  // wins from K = 512 up (3x3 convs, 1x1 convs with >= 512 input channels: +2..6 % at K = 512; K = 256 loses: one workgroup per
   // CU cannot hide its prologue / epilogue behind so few K units); the data gradient wins at every K that occurs (>= 128), its
   // 128-row counterpart pays more for the scattered / accumulating epilogue.  Both need enough rows to fill the chip once.
-  return g.M >= 256 * 64 && g.Ktot >= (dgrad ? 128 : 1024);
+  static const int kmin_f = []() { const char* e = getenv("EDRL_V3_FWD_KMIN"); return e ? atoi(e) : 512; }();
+  return g.M >= 256 * 64 && g.Ktot >= (dgrad ? 128 : kmin_f);
 }
 
 int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st) {
