@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "conv_geom.h"
+#include <type_traits>
 #include "conv_bf16_v3.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -272,157 +273,192 @@ __global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* 
     __syncthreads();
   }
 
-  // ---- vector epilogue through LDS (fp32 staging): lane owns 4 consecutive channels of one pixel -> 8-byte bf16 store
+  // ---- vector epilogue through LDS (fp32 staging): a lane owns VW consecutive channels of one pixel.  VW = 8 (16-byte bf16 stores and
+  // operand loads) whenever the channel count and the pointers allow: with 8-byte stores the epilogue is store-ISSUE-bound (twice
+  // the store instructions for the same bytes; MI355X_MICROARCH.md "epilogue store tail"), and the short-K layers of stages 1-2 are
+  // all epilogue.  VW = 4 keeps channel counts that are multiples of 4 only.
   const bool accum = g.flags & GF_ACCUM;
   const bool stats = EPI == 0 && (g.flags & GF_STATS) != 0;
-  constexpr int SLD = WN + 4;
-  constexpr int C4 = WN / 4;
-  constexpr int RPP2 = 64 / C4;
-  float* stage = smem + wave * 32 * SLD;
-  const int srow = lane / C4, sc4 = lane % C4;
-  const int n = n0 + wn0 + sc4 * 4;
-  f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 e_scale = {0.f, 0.f, 0.f, 0.f}, e_shift2 = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (EPI == 1) {
-    if (n < g.NC && !F.ep_mask) {
-      e_scale = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + n);
-      e_shift2 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + n);
-    }
-  }
-  constexpr int NT = 32 / RPP2;       // row passes per 32-row tile
+  auto epilogue = [&](auto VW_) {
+    constexpr int VW = decltype(VW_)::value;
+    constexpr int Q = VW / 4;              // f32x4 quads per lane
+    constexpr int SLD = WN + 4;
+    constexpr int CV = WN / VW;            // lanes per staged row
+    constexpr int RPP2 = 64 / CV;          // rows per pass of the wave
+    constexpr int NT = 32 / RPP2;          // row passes per 32-row tile
+    typedef __bf16 bf16xv __attribute__((ext_vector_type(VW)));
+    float* stage = smem + wave * 32 * SLD;
+    const int srow = lane / CV, scv = lane % CV;
+    const int n = n0 + wn0 + scv * VW;
+    f32x4 kshift[Q], st0[Q], st1[Q], e_scale[Q], e_shift2[Q];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    // Every global operand of this 32-row tile's epilogue (the accumulate target, the raw tensor of the BatchNorm below and its
-    // sign bytes) is requested up front -- NT loads in flight per lane behind the LDS transpose instead of one exposed HBM round
-    // trip per row pass (the expanding 1x1 data gradients of stages 1-2, K = 64 / 128, are all epilogue: 2.7 -> TB/s figures in
-    // DESIGN.md section 3b).
-    long pixs[NT];
-    bool oks[NT];
-    bf16x4 o_pre[NT], x_pre[NT];
-    int mb_pre[NT];
+    for (int q = 0; q < Q; ++q) kshift[q] = st0[q] = st1[q] = e_scale[q] = e_shift2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == 1) {
+      if (n < g.NC && !F.ep_mask) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int row = t * RPP2 + srow;
-      const long m = m0 + wm0 + i * 32 + row;
-      oks[t] = m < g.M && n < g.NC;
-      long pix = m;
-      if (DGRAD && g.step > 1 && oks[t]) {
-        const int ohw = g.OHs * g.OWs;
-        const int nn = (int)(m / ohw);
-        const int rem = (int)(m - (long)nn * ohw);
-        const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
-        pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
-      }
-      pixs[t] = pix;
-      mb_pre[t] = 0;
-      if (oks[t]) {
-        if (accum) o_pre[t] = *reinterpret_cast<const bf16x4*>(dst + pix * g.ld_dst + n);
-        if constexpr (EPI == 1) {
-          x_pre[t] = *reinterpret_cast<const bf16x4*>((const __bf16*)F.ep_x + pix * F.ld_ep + n);
-          if (F.ep_mask) mb_pre[t] = F.ep_mask[pix * (long)(g.NC >> 2) + (n >> 2)];
+        for (int q = 0; q < Q; ++q) {
+          e_scale[q] = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + n + 4 * q);
+          e_shift2[q] = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + n + 4 * q);
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i) {
+      // Every global operand of this 32-row tile's epilogue (the accumulate target, the raw tensor of the BatchNorm below and its
+      // sign bytes) is requested up front -- NT loads in flight per lane behind the LDS transpose instead of one exposed HBM round
+      // trip per row pass (the expanding 1x1 data gradients of stages 1-2, K = 64 / 128, are all epilogue: DESIGN.md section 3b).
+      int pixs[NT];                        // destination pixel (< 2^31: checked by the C-ABI launchers), -1 = row / column outside
+      bf16xv o_pre[NT], x_pre[NT];
+      int mb_pre[NT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
-    // per-wave staging region and per-wave BatchNorm shift (its own first row): wave-local fences, no workgroup barrier
-    // (same scheme as conv_gemm.hip's epilogue; the row halves are re-based when combined below)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (stats && i == 0) kshift = *reinterpret_cast<const f32x4*>(stage + sc4 * 4);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int row = t * RPP2 + srow;
-      if (oks[t]) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SLD + sc4 * 4);
-        if (stats) { const f32x4 d = v - kshift; st0 += d; st1 += d * d; }
-        __bf16* p = dst + pixs[t] * g.ld_dst + n;
-        if (accum) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)o_pre[t][e];
+      for (int t = 0; t < NT; ++t) {
+        const int row = t * RPP2 + srow;
+        const long m = m0 + wm0 + i * 32 + row;
+        const bool okt = m < g.M && n < g.NC;
+        long pix = m;
+        if (DGRAD && g.step > 1 && okt) {
+          const int ohw = g.OHs * g.OWs;
+          const int nn = (int)(m / ohw);
+          const int rem = (int)(m - (long)nn * ohw);
+          const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+          pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
         }
-        if constexpr (EPI == 1) {
-          f32x4 xr;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xr[e] = (float)x_pre[t][e];
-          if (F.ep_mask) {
-            const int mb = mb_pre[t];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (mb >> e) & 1 ? v[e] : 0.f;
-          } else if (g.flags & GF_EPI_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xr[e], e_scale[e], e_shift2[e]) > 0.f ? v[e] : 0.f;
+        pixs[t] = okt ? (int)pix : -1;
+        mb_pre[t] = 0;
+        if (okt) {
+          if (accum) o_pre[t] = *reinterpret_cast<const bf16xv*>(dst + pix * g.ld_dst + n);
+          if constexpr (EPI == 1) {
+            x_pre[t] = *reinterpret_cast<const bf16xv*>((const __bf16*)F.ep_x + pix * F.ld_ep + n);
+            if (F.ep_mask) {
+              const unsigned char* mp = F.ep_mask + pix * (long)(g.NC >> 2) + (n >> 2);
+              if constexpr (VW == 8) mb_pre[t] = *reinterpret_cast<const unsigned short*>(mp);     // bytes of channels n..n+3, n+4..n+7
+              else mb_pre[t] = *mp;
+            }
           }
-          st0 += v;
-          st1 = __builtin_elementwise_fma(v, xr, st1);
         }
-        bf16x4 ov;
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = (__bf16)v[e];
-        *reinterpret_cast<bf16x4*>(p) = ov;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + j * 32 + li] = acc[i][j][r];
+      // per-wave staging region and per-wave BatchNorm shift (its own first row): wave-local fences, no workgroup barrier
+      // (same scheme as conv_gemm.hip's epilogue; the row halves are re-based when combined below)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (stats && i == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) kshift[q] = *reinterpret_cast<const f32x4*>(stage + scv * VW + 4 * q);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int row = t * RPP2 + srow;
+        if (pixs[t] >= 0) {
+          bf16xv ov;
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SLD + scv * VW + 4 * q);
+            if (stats) { const f32x4 d = v - kshift[q]; st0[q] += d; st1[q] += d * d; }
+            if (accum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)o_pre[t][4 * q + e];
+            }
+            if constexpr (EPI == 1) {
+              f32x4 xr;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) xr[e] = (float)x_pre[t][4 * q + e];
+              if (F.ep_mask) {
+                const int mb = mb_pre[t] >> (8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (mb >> e) & 1 ? v[e] : 0.f;
+              } else if (g.flags & GF_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xr[e], e_scale[q][e], e_shift2[q][e]) > 0.f ? v[e] : 0.f;
+              }
+              st0[q] += v;
+              st1[q] = __builtin_elementwise_fma(v, xr, st1[q]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[4 * q + e] = (__bf16)v[e];
+          }
+          *reinterpret_cast<bf16xv*>(dst + (long)pixs[t] * g.ld_dst + n) = ov;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if constexpr (EPI == 1) {
+#pragma unroll
+      for (int o = 32; o >= CV; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { st0[q][e] += __shfl_xor(st0[q][e], o, 64); st1[q][e] += __shfl_xor(st1[q][e], o, 64); }
+      }
+      float* red = smem + 4 * 32 * SLD;          // [wave][2][WN]
+      if (srow == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            red[(wave * 2 + 0) * WN + scv * VW + 4 * q + e] = st0[q][e];
+            red[(wave * 2 + 1) * WN + scv * VW + 4 * q + e] = st1[q][e];
+          }
+      }
+      __syncthreads();
+      if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
+        float* pp = F.ep_part + ((long)F.ep_chunk0 + tile_m) * 2 * g.NC;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cc = scv * VW + 4 * q + e;
+            pp[n + 4 * q + e] = st0[q][e] + red[((wave + 2) * 2 + 0) * WN + cc];
+            pp[g.NC + n + 4 * q + e] = st1[q][e] + red[((wave + 2) * 2 + 1) * WN + cc];
+          }
+      }
+      return;
+    }
+    if (stats) {
+#pragma unroll
+      for (int o = 32; o >= CV; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { st0[q][e] += __shfl_xor(st0[q][e], o, 64); st1[q][e] += __shfl_xor(st1[q][e], o, 64); }
+      }
+      float* red = smem + 4 * 32 * SLD;          // [wave][3][WN] = (S1, S2, K)
+      if (srow == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            red[(wave * 3 + 0) * WN + scv * VW + 4 * q + e] = st0[q][e];
+            red[(wave * 3 + 1) * WN + scv * VW + 4 * q + e] = st1[q][e];
+            red[(wave * 3 + 2) * WN + scv * VW + 4 * q + e] = kshift[q][e];
+          }
+      }
+      __syncthreads();
+      if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
+        float* pp = g.stat_part + (long)tile_m * 3 * g.NC;
+        long nl = g.M - (m0 + WM);
+        const float nb = nl <= 0 ? 0.f : (nl > WM ? (float)WM : (float)nl);
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cc = scv * VW + 4 * q + e;
+            const float s1b = red[((wave + 2) * 3 + 0) * WN + cc], s2b = red[((wave + 2) * 3 + 1) * WN + cc];
+            const float d = red[((wave + 2) * 3 + 2) * WN + cc] - kshift[q][e];
+            pp[n + 4 * q + e] = st0[q][e] + (s1b + nb * d);
+            pp[g.NC + n + 4 * q + e] = st1[q][e] + (s2b + 2.f * d * s1b + nb * d * d);
+            pp[2 * g.NC + n + 4 * q + e] = kshift[q][e];
+          }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  if constexpr (EPI == 1) {
-#pragma unroll
-    for (int o = 32; o >= C4; o >>= 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
-    }
-    float* red = smem + 4 * 32 * SLD;          // [wave][2][WN]
-    if (srow == 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        red[(wave * 2 + 0) * WN + sc4 * 4 + e] = st0[e];
-        red[(wave * 2 + 1) * WN + sc4 * 4 + e] = st1[e];
-      }
-    }
-    __syncthreads();
-    if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
-      float* pp = F.ep_part + ((long)F.ep_chunk0 + tile_m) * 2 * g.NC;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int cc = sc4 * 4 + e;
-        pp[n + e] = st0[e] + red[((wave + 2) * 2 + 0) * WN + cc];
-        pp[g.NC + n + e] = st1[e] + red[((wave + 2) * 2 + 1) * WN + cc];
-      }
-    }
-    return;
-  }
-  if (stats) {
-#pragma unroll
-    for (int o = 32; o >= C4; o >>= 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { st0[e] += __shfl_xor(st0[e], o, 64); st1[e] += __shfl_xor(st1[e], o, 64); }
-    }
-    float* red = smem + 4 * 32 * SLD;          // [wave][3][WN] = (S1, S2, K)
-    if (srow == 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        red[(wave * 3 + 0) * WN + sc4 * 4 + e] = st0[e];
-        red[(wave * 3 + 1) * WN + sc4 * 4 + e] = st1[e];
-        red[(wave * 3 + 2) * WN + sc4 * 4 + e] = kshift[e];
-      }
-    }
-    __syncthreads();
-    if ((wave >> 1) == 0 && srow == 0 && n < g.NC) {
-      float* pp = g.stat_part + (long)tile_m * 3 * g.NC;
-      long nl = g.M - (m0 + WM);
-      const float nb = nl <= 0 ? 0.f : (nl > WM ? (float)WM : (float)nl);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int cc = sc4 * 4 + e;
-        const float s1b = red[((wave + 2) * 3 + 0) * WN + cc], s2b = red[((wave + 2) * 3 + 1) * WN + cc];
-        const float d = red[((wave + 2) * 3 + 2) * WN + cc] - kshift[e];
-        pp[n + e] = st0[e] + (s1b + nb * d);
-        pp[g.NC + n + e] = st1[e] + (s2b + 2.f * d * s1b + nb * d * d);
-        pp[2 * g.NC + n + e] = kshift[e];
-      }
-    }
-  }
+  };
+  const bool wide = (g.flags & GF_EPI_VW4) == 0 && (g.NC & 7) == 0 && (g.ld_dst & 7) == 0 && (((uintptr_t)dst) & 15) == 0 &&
+                    (EPI == 0 || ((F.ld_ep & 7) == 0 && (((uintptr_t)F.ep_x) & 15) == 0));
+  if (wide) epilogue(std::integral_constant<int, 8>{});
+  else epilogue(std::integral_constant<int, 4>{});
 }
 
 template <int BN, bool DGRAD, bool BUF, int ATR = 0, int EPI = 0, bool MASK = true>
@@ -443,7 +479,9 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   }
   GatherFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, g, tiles_n, F);
+  GatherGeom gm = g;
+  { const char* e = getenv("EDRL_BF16_EPI_VW4"); if (e && e[0] == '1') gm.flags |= GF_EPI_VW4; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, gm, tiles_n, F);
   EDRL_LAUNCH_CHECK();
   return 0;
 }
