@@ -33,8 +33,10 @@ typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
 //   EPI 1: the computed tile is the gradient of a BatchNorm(+ReLU) output: masked (sign bytes or decision re-derived from the
 //          raw tensor), stored as bf16, and (sum g, sum g*x) of the UNROUNDED fp32 values go to ep_part.
 //   MASK : padding taps / masked rows must read as exactly 0 after the transform (false for 1x1 / pad-0 layers).
-template <int BN, bool DGRAD, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true>
-__global__ __launch_bounds__(256, 3) void conv_gather_bf16_kernel(const __bf16* __restrict__ src,
+// OCC4: compiled for 4 workgroups per CU (128 VGPRs, 4 x 40 KiB of LDS): the forward with the operand transform (ATR 1), whose
+// short-K layers are latency-bound at 3.
+template <int BN, bool DGRAD, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true, bool OCC4 = false>
+__global__ __launch_bounds__(256, OCC4 ? 4 : 3) void conv_gather_bf16_kernel(const __bf16* __restrict__ src,
                                                                   const __bf16* __restrict__ wm,
                                                                   __bf16* __restrict__ dst, GatherGeom g, int tiles_n,
                                                                   GatherFuse F) {
@@ -471,16 +473,27 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   size_t lds = (size_t)2 * (128 + BN) * HLD * sizeof(__bf16);
   const size_t epi = (size_t)(4 * 32 * (BN / 2 + 4) + 4 * 3 * (BN / 2)) * sizeof(float);
   if (epi > lds) lds = epi;
+  GatherFuse F;
+  if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
+  GatherGeom gm = g;
+  { const char* e = getenv("EDRL_BF16_EPI_VW4"); if (e && e[0] == '1') gm.flags |= GF_EPI_VW4; }
+  if constexpr (ATR == 1 && EPI == 0 && !DGRAD) {
+    const char* e = getenv("EDRL_BF16_FWD_OCC4");            // (A/B switch, read per call)
+    if (!(e && e[0] == '0')) {
+      auto k4 = conv_gather_bf16_kernel<BN, DGRAD, BUF, ATR, EPI, MASK, true>;
+      static bool attr4 = false;
+      if (!attr4) { (void)hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr4 = true; }
+      hipLaunchKernelGGL(k4, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, gm, tiles_n, F);
+      EDRL_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   auto kern = conv_gather_bf16_kernel<BN, DGRAD, BUF, ATR, EPI, MASK>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  GatherFuse F;
-  if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
-  GatherGeom gm = g;
-  { const char* e = getenv("EDRL_BF16_EPI_VW4"); if (e && e[0] == '1') gm.flags |= GF_EPI_VW4; }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, gm, tiles_n, F);
   EDRL_LAUNCH_CHECK();
   return 0;
