@@ -912,6 +912,8 @@ int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat
     g.stat_part = stat_part;
   }
   if (gather_bf16_v3_ok(g, false)) return launch_gather_bf16_v3(x, w, y, g, false, st);      // K-heavy layers: 256x256 LDS-DMA core
+  if (Hi == Ho && Wi == Wo && !((uintptr_t)y & 15) && conv3x3_c64_ok(N, Hi, Wi, Ci, Co, KH, KW, stride, pad))
+    return launch_conv3x3_c64(x, w, 0, y, N, Hi, Wi, stat_part, nullptr, nullptr, nullptr, st);   // 64 -> 64 3x3: weight-stationary kernel
   if (Co <= 64) return launch_gather_bf16<64, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
   return launch_gather_bf16<128, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
 }
@@ -924,6 +926,8 @@ int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N,
     return EDRL_EINVAL;
   if (((uintptr_t)dy & 15) || ((uintptr_t)wt & 15) || ((uintptr_t)dx & 7)) return EDRL_EINVAL;
   if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
+  if (!(flags & GF_ACCUM) && Hi == Ho && Wi == Wo && !((uintptr_t)dx & 15) && conv3x3_c64_ok(N, Hi, Wi, Co, Ci, KH, KW, stride, pad))
+    return launch_conv3x3_c64(dy, wt, 1, dx, N, Hi, Wi, nullptr, nullptr, nullptr, nullptr, st);
   int sshift = 0;
   while ((1 << sshift) < stride) ++sshift;
   if ((1 << sshift) != stride) return EDRL_EINVAL;
@@ -1122,6 +1126,9 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
       chunks += ((long)N * ohs * ows + 127) / 128;
     }
   if (ep_raw && ep_part_bytes < (size_t)chunks * 2 * Ci * sizeof(float)) return EDRL_ENOSPC;
+  if (plain_in && ep_mask && !(flags & GF_ACCUM) && Hi == Ho && Wi == Wo && !((uintptr_t)dx & 15) && !((uintptr_t)ep_raw & 15) &&
+      conv3x3_c64_ok(N, Hi, Wi, Co, Ci, KH, KW, stride, pad))
+    return launch_conv3x3_c64(g_in, wt, 1, dx, N, Hi, Wi, nullptr, ep_raw, ep_mask, ep_part, st);
   int sshift = 0;
   while ((1 << sshift) < stride) ++sshift;
   if ((1 << sshift) != stride) return EDRL_EINVAL;

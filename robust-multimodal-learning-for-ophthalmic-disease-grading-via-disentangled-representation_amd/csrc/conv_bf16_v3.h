@@ -14,3 +14,9 @@ bool wgrad_bf16_v3_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int
 size_t wgrad_bf16_v3_workspace_bytes(int N, int Ho, int Wo, int Co, int Ci, int KH, int KW);
 int launch_wgrad_bf16_v3(const void* dy, const void* x, float* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int Ci,
                          int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int* splits_out, hipStream_t st);
+
+// 3x3 / stride 1 / pad 1 between two 64-channel tensors on the weight-stationary kernel of conv_c64_bf16.hip (forward, flip = 0, with
+// optional BatchNorm chunk partials; data gradient, flip = 1 on the permuted weights, optionally with the masked-gradient epilogue).
+bool conv3x3_c64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride, int pad);
+int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int N, int H, int W, float* stat_part, const void* ep_x,
+                       const unsigned char* ep_mask, float* ep_part, hipStream_t st);

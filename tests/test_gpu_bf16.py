@@ -124,6 +124,63 @@ def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
         check(f"v3 vs v2 conv_dgrad{case}", dv, outs["0"][2], BF16_TOL)
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 14, 14), (3, 9, 7), (1, 2, 2), (5, 16, 13), (1, 23, 3)])
+def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, monkeypatch):
+    """The weight-stationary 64 -> 64 3x3 kernel (csrc/conv_c64_bf16.hip; weights in LDS in fragment order, pixel fragments straight
+    from global memory, lane-pair swap for 16-byte stores), forced on (EDRL_BF16_C64=2) at sizes far below its production range --
+    pixel counts that are not multiples of 16 / 64 / 128, 2x2 images (every tap but the centre row / column masked), several images
+    per block -- forward with BatchNorm chunk partials, plain data gradient, and the data gradient with the masked-gradient epilogue,
+    against fp64 (one bf16 ulp of the output range; partial sums 1e-3 of their scale: they come from the unrounded accumulators)
+    and against the 128-row kernel (EDRL_BF16_C64=0)."""
+    ops, L = edrl.ops, edrl._lib
+    P = L.ptr
+    C = 64
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, H, W, C, generator=g).bfloat16()
+    w = (torch.randn(C, 3, 3, C, generator=g) * 0.1).bfloat16()
+    xd = nchw(x.double()).requires_grad_(True)
+    wd = w.double().permute(0, 3, 1, 2).contiguous()
+    y = F.conv2d(xd, wd, padding=1)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.double())
+    M = N * H * W
+    xraw = torch.randn(N, H, W, C, generator=g).bfloat16()                    # raw tensor of the BatchNorm below (epilogue operand)
+    mask = torch.randint(0, 16, (M, C // 4), generator=g, dtype=torch.uint8)
+    fc = torch.ones(5, C)
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("EDRL_BF16_C64", mode)
+        yh, part, chunks = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), 1, 1, stats=True)
+        wt = ops.permute_weight_bf16(w.float().to(dev))
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+        dxh = ops.conv2d_dgrad_bf16(dyh, wt, (N, H, W, C), 1, 1)
+        gm, epart, _ = ops.conv2d_dgrad_bn_bf16(dyh, None, None, wt, (N, H, W, C), 1, 1, ep=(xraw.to(dev), mask.to(dev), fc.to(dev), True))
+        torch.cuda.synchronize()
+        outs[mode] = (yh.float().cpu(), part.cpu(), dxh.float().cpu(), gm.float().cpu(), epart.cpu())
+    yv, pv, dv, gv, ev = outs["2"]
+    check(f"c64 fwd {N}x{H}x{W}", nchw(yv), y, BF16_TOL)
+    check(f"c64 fwd vs 128-row {N}x{H}x{W}", yv, outs["0"][0], BF16_TOL)
+    rows = y.detach().permute(0, 2, 3, 1).reshape(-1, C)
+    assert pv.shape[0] == (M + 127) // 128
+    for c in range(pv.shape[0]):
+        blk = rows[c * 128:min(M, (c + 1) * 128)]
+        K = pv[c, 2].double()
+        assert float((K - blk[0]).abs().max()) <= BF16_TOL * float(rows.abs().max()), "shift = the chunk's first row"
+        d = blk - K
+        assert float((pv[c, 0].double() - d.sum(0)).abs().max()) <= 1e-3 * max(float(d.abs().sum(0).max()), 1e-6), f"chunk {c} S1"
+        assert float((pv[c, 1].double() - (d * d).sum(0)).abs().max()) <= 1e-3 * max(float((d * d).sum(0).max()), 1e-6), f"chunk {c} S2"
+    check(f"c64 dgrad {N}x{H}x{W}", nchw(dv), xd.grad, BF16_TOL)
+    check(f"c64 dgrad vs 128-row {N}x{H}x{W}", dv, outs["0"][2], BF16_TOL)
+    keep = ((mask.view(M, C // 4, 1).int() >> torch.arange(4).view(1, 1, 4)) & 1).view(N, H, W, C).double()
+    gref = xd.grad.permute(0, 2, 3, 1) * keep
+    check(f"c64 masked dgrad {N}x{H}x{W}", gv.double(), gref, BF16_TOL)
+    for c in range(ev.shape[0]):
+        gb = gref.reshape(-1, C)[c * 128:min(M, (c + 1) * 128)]
+        xb = xraw.double().reshape(-1, C)[c * 128:min(M, (c + 1) * 128)]
+        assert float((ev[c, 0].double() - gb.sum(0)).abs().max()) <= 1e-3 * max(float(gb.abs().sum(0).max()), 1e-6), f"chunk {c} sum g"
+        assert float((ev[c, 1].double() - (gb * xb).sum(0)).abs().max()) <= 1e-3 * max(float((gb * xb).abs().sum(0).max()), 1e-6), f"chunk {c} sum g*x"
+
+
 W3_CASES = [
     # N, Ci, H, W, Co, k, s, p : both channel counts multiples of 256 (the v3 weight-gradient core's domain); pixel counts that
     # are not multiples of the 32-pixel unit, fewer units than the 3-deep prefetch, padding taps, stride 2 (odd sizes: the last
