@@ -251,8 +251,11 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : 3) void conv_gather_bf16_kernel(con
   const int li = lane & 31, lh = lane >> 5;
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    advance();
-    load_tile();                          // next tile's loads first; consumed after the MFMA chain
+    const bool more = kt + 1 < KT || (g.flags & GF_KTAIL);        // (wave-uniform) the last tile issues no loads: at K = 64 / 128 -- the short-K layers of
+    if (more) {                           // stages 1-2 -- a past-the-end load round and its transform / LDS store were a third /
+      advance();                          // a fifth of the loop
+      load_tile();                        // next tile's loads first; consumed after the MFMA chain
+    }
     __builtin_amdgcn_sched_barrier(0);
     const __bf16* a = As + buf * BM * HLD + (wm0 + li) * HLD + 8 * lh;
     const __bf16* b = Bs + buf * BN * HLD + (wn0 + li) * HLD + 8 * lh;
@@ -270,8 +273,10 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : 3) void conv_gather_bf16_kernel(con
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    transform_tile();
-    store_tile(buf ^ 1);
+    if (more) {
+      transform_tile();
+      store_tile(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -477,6 +482,7 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   GatherGeom gm = g;
   { const char* e = getenv("EDRL_BF16_EPI_VW4"); if (e && e[0] == '1') gm.flags |= GF_EPI_VW4; }
+  { const char* e = getenv("EDRL_BF16_KTAIL"); if (e && e[0] == '1') gm.flags |= GF_KTAIL; }     // (A/B) keep the past-the-end load round
   if constexpr (ATR == 1 && EPI == 0 && !DGRAD) {
     const char* e = getenv("EDRL_BF16_FWD_OCC4");            // (A/B switch, read per call)
     if (!(e && e[0] == '0')) {

@@ -63,4 +63,5 @@ struct GatherFuse {
 #define GF_STATS 8     // emit BatchNorm chunk partials from the vector epilogue
 #define GF_EPI_RELU 16 // EPI 1 without sign bytes: the BatchNorm whose backward is reduced was followed by a ReLU
 #define GF_LEAN_STRIDED 32  // set by the launcher: the per-workgroup destination footprint of a strided parity class fits a 2 GiB descriptor
+#define GF_KTAIL 128         // (bf16 128-row kernel, A/B switch EDRL_BF16_KTAIL=1) issue the load round past the last K tile as before
 #define GF_EPI_VW4 64       // (bf16 128-row kernel, A/B switch EDRL_BF16_EPI_VW4=1) keep the 4-channel epilogue lanes
