@@ -291,6 +291,193 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_bf16_kernel(const __bf16* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution with 64 input channels (K = 64: two MFMA K steps) and NC = 64 .. 512 output channels: the EXPANDING layers of the
+// first residual stage (layer1.*.conv3 with the BatchNorm + ReLU of its input folded into the operand, layer1.0.downsample).  They are
+// pure streaming -- 16 KiB in, NC/64 x 16 KiB out per 128 pixels, 0.1 us of MFMA -- and the 128-row kernel spends 10 us per 128 x 128
+// tile on them (one tile per workgroup: prologue, two K tiles, epilogue; 3.0 TB/s).  Same skeleton as the 3x3 kernel above: weights
+// resident in LDS in fragment order, a wave owns 128 pixels x ALL output channels, pixel fragments loaded straight into registers
+// once per chunk (and transformed there: ATR 1 = bf16(relu(x*scale + shift2)), the arithmetic of conv_bf16.hip's operand transform),
+// then NC/64 passes of 2 x 32 MFMAs over the same fragments, each with the c64 epilogue (permlane16_swap -> 16-byte stores, BatchNorm
+// chunk partials of its 64 channels from the fp32 accumulators).  No barrier, no LDS traffic for the pixels; the HBM queue is kept
+// full by the 8 independent waves per CU.
+template <int ATR>
+__global__ __launch_bounds__(512, 2) void conv1x1_k64_bf16_kernel(const __bf16* __restrict__ src, const __bf16* __restrict__ w,
+                                                                  __bf16* __restrict__ dst, int M, int NC, int nchunks,
+                                                                  const float* __restrict__ fcoef, float* __restrict__ stat_part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nct = NC >> 4;
+  // weights [NC][64] -> LDS fragment order [ks 2][channel tile][lane]: lane l = (channel 16 ct + (l&15), k 32 ks + 8 (l>>4) .. +7)
+  for (int idx = tid; idx < 2 * nct * 64; idx += 512) {
+    const int l = idx & 63, ct = (idx >> 6) % nct, ks = (idx >> 6) / nct;
+    *reinterpret_cast<c64_bf16x8*>(smem + idx * 16) =
+        *reinterpret_cast<const c64_bf16x8*>(w + (long)(16 * ct + (l & 15)) * 64 + 32 * ks + 8 * (l >> 4));
+  }
+  float* tco = reinterpret_cast<float*>(smem + NC * 128);       // ATR 1: [scale 64][shift2 64] of the input BatchNorm, behind the weights
+  if constexpr (ATR == 1) {
+    if (tid < 128) tco[tid] = fcoef[(tid < 64 ? 2 : 4) * 64 + (tid & 63)];
+  }
+  __syncthreads();
+  const int pl = lane & 15, gq = lane >> 4;
+  const bool even = (gq & 1) == 0;
+  const int cb0 = even ? 4 * gq : 16 + 4 * (gq - 1);
+  auto rowsum = [&](float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+    return x;
+  };
+  const unsigned char* wl = smem + lane * 16;
+  for (int chunk = blockIdx.x * 8 + wave; chunk < nchunks; chunk += gridDim.x * 8) {
+    const int m0 = chunk * 128;
+    // ---- the chunk's pixel fragments: 8 column tiles x 2 K steps, 16 bytes per lane each
+    c64_bf16x8 a[8][2];
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+      const int m = m0 + 16 * pt + pl;
+      const long mo = (long)(m < M ? m : M - 1) * 64;            // (rows past the end: a valid address, results never stored)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[pt][ks] = *reinterpret_cast<const c64_bf16x8*>(src + mo + 32 * ks + 8 * gq);
+    }
+    if constexpr (ATR == 1) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 tsc[2], tsh[2];            // scale / shift2 of this lane's input channels 32 ks + 8 gq + 4 h .. +3 (from LDS: no registers held)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          tsc[h] = *reinterpret_cast<const f32x4*>(tco + 32 * ks + 8 * gq + 4 * h);
+          tsh[h] = *reinterpret_cast<const f32x4*>(tco + 64 + 32 * ks + 8 * gq + 4 * h);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) {
+          c64_bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o[e] = (__bf16)fmaxf(__builtin_fmaf((float)a[pt][ks][e], tsc[e >> 2][e & 3], tsh[e >> 2][e & 3]), 0.f);
+          a[pt][ks] = o;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);       // (keeps the transform's temporaries out of the pass loop's register budget)
+    }
+#pragma unroll 1
+    for (int q = 0; q < (NC >> 6); ++q) {
+      f32x4 sa[4], sb[4], kk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sa[j] = sb[j] = kk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          c64_bf16x8 wf[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) wf[ct] = *reinterpret_cast<const c64_bf16x8*>(wl + ((ks * nct + 4 * q + ct) << 10));
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+              acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct], a[4 * blk + pt][ks], acc[ct][pt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+          f32x4 v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto p0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][pt][e]), __float_as_uint(acc[1][pt][e]), false, false);
+            const auto p1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2][pt][e]), __float_as_uint(acc[3][pt][e]), false, false);
+            v[0][e] = __uint_as_float(p0[0]); v[1][e] = __uint_as_float(p0[1]);
+            v[2][e] = __uint_as_float(p1[0]); v[3][e] = __uint_as_float(p1[1]);
+          }
+          const int m = m0 + 64 * blk + 16 * pt + pl;
+          const bool ok = m < M;
+          if (stat_part) {
+            if (blk == 0 && pt == 0) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kk[j][e] = __shfl(v[j][e], lane & 48, 64);      // the chunk's first row
+            }
+            if (ok) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { const f32x4 d = v[j] - kk[j]; sa[j] += d; sb[j] = __builtin_elementwise_fma(d, d, sb[j]); }
+            }
+          }
+          if (ok) {
+            c64_bf16x8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o0[e] = (__bf16)v[0][e]; o0[4 + e] = (__bf16)v[1][e];
+              o1[e] = (__bf16)v[2][e]; o1[4 + e] = (__bf16)v[3][e];
+            }
+            __bf16* dp = dst + (long)m * NC + 64 * q + cb0;
+            *reinterpret_cast<c64_bf16x8*>(dp) = o0;
+            *reinterpret_cast<c64_bf16x8*>(dp + 32) = o1;
+          }
+        }
+      }
+      if (stat_part) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sa[j][e] = rowsum(sa[j][e]); sb[j][e] = rowsum(sb[j][e]); }
+        if (pl == 15) {
+          float* pp = stat_part + (long)chunk * 3 * NC + 64 * q;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = cb0 + 4 * (j & 1) + 32 * (j >> 1);
+            *reinterpret_cast<f32x4*>(pp + c) = sa[j];
+            *reinterpret_cast<f32x4*>(pp + NC + c) = sb[j];
+            *reinterpret_cast<f32x4*>(pp + 2 * (long)NC + c) = kk[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+bool conv1x1_k64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride, int pad) {
+  const char* env = getenv("EDRL_BF16_K64");           // 0 off, 1 auto (default), 2 wherever the geometry allows (read per call)
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0) return false;
+  if (Ci != 64 || (Co % 64) || Co < 64 || Co > 512 || KH != 1 || KW != 1 || stride != 1 || pad != 0 || N <= 0) return false;
+  const long M = (long)N * H * W;
+  if (M > 0x7fffff00L) return false;
+  return mode == 2 || (M >= 128L * 2048 && Co >= 128);     // streaming layers only: below that the 128-row kernel's grid fills the chip
+}
+
+// y [M][Co] = conv1x1(x [M][64] (ATR: relu(x*scale + shift2) with in_fcoef [5][64]), w [Co][64]); stat_part optional.
+int launch_conv1x1_k64(const void* x, const float* in_fcoef, const void* w, void* y, int N, int H, int W, int Co, float* stat_part,
+                       hipStream_t st) {
+  const long M = (long)N * H * W;
+  const int nchunks = (int)((M + 127) / 128);
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return EDRL_EINVAL;
+  int grid = (nchunks + 7) / 8;
+  if (grid > 256) grid = 256;
+  const int lds = Co * 64 * 2 + 512;
+  if (in_fcoef) {
+    auto kern = conv1x1_k64_bf16_kernel<1>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 2 + 512); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const __bf16*)x, (const __bf16*)w, (__bf16*)y, (int)M, Co, nchunks,
+                       in_fcoef, stat_part);
+  } else {
+    auto kern = conv1x1_k64_bf16_kernel<0>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 2 + 512); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const __bf16*)x, (const __bf16*)w, (__bf16*)y, (int)M, Co, nchunks,
+                       (const float*)nullptr, stat_part);
+  }
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
 static int c64_ceil_log2(unsigned d) {
   int s = 0;
   while ((1u << s) < d) ++s;

@@ -181,6 +181,46 @@ def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, monkey
         assert float((ev[c, 1].double() - (gb * xb).sum(0)).abs().max()) <= 1e-3 * max(float((gb * xb).abs().sum(0).max()), 1e-6), f"chunk {c} sum g*x"
 
 
+@pytest.mark.parametrize("M_hw,Co", [((2, 14, 14), 256), ((3, 9, 7), 128), ((1, 5, 5), 64), ((5, 16, 13), 512)])
+def test_conv1x1_k64_streaming_kernel_vs_fp64_and_128row_kernel(edrl, dev, M_hw, Co, monkeypatch):
+    """The streaming 64 -> Co 1x1 kernel (csrc/conv_c64_bf16.hip: weights in LDS, a wave owns 128 pixels x all output channels, pixel
+    fragments loaded and transformed in registers once per chunk), forced on (EDRL_BF16_K64=2) at small sizes (pixel counts off every
+    tile size, one case below a single chunk): plain forward with BatchNorm chunk partials and the fused form (BatchNorm + ReLU of the
+    input in the operand), against fp64 of the same bf16 operands (one bf16 ulp; partials 1e-3 of their scale) and against the
+    128-row kernel (EDRL_BF16_K64=0), which forms the same transformed operand (same fp32 arithmetic, one rounding)."""
+    ops, L = edrl.ops, edrl._lib
+    N, H, W = M_hw
+    C = 64
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(N, H, W, C, generator=g).bfloat16()
+    w = (torch.randn(Co, 1, 1, C, generator=g) * 0.2).bfloat16()
+    fc = torch.zeros(5, C)
+    fc[2] = 0.5 + torch.rand(C, generator=g); fc[4] = 0.3 * torch.randn(C, generator=g)
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("EDRL_BF16_K64", mode)
+        y0, p0, ch = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), 1, 0, stats=True)
+        y1, p1, _ = ops.conv2d_fwd_bnin_stats_bf16(x.to(dev), fc.to(dev), w.to(dev), 1, 0)
+        torch.cuda.synchronize()
+        outs[mode] = (y0.float().cpu(), p0.cpu(), y1.float().cpu(), p1.cpu())
+    M = N * H * W
+    wd = w.double().view(Co, C)
+    act = torch.relu(x.float() * fc[2] + fc[4]).bfloat16().double().view(M, C)      # the operand the kernels form: fp32 fma, one rounding
+    for name, xin, (yv, pv), (yo, _) in (("plain", x.double().view(M, C), outs["2"][0:2], outs["0"][0:2]),
+                                         ("fused", act, outs["2"][2:4], outs["0"][2:4])):
+        ref = xin @ wd.t()
+        check(f"k64 {name} {M_hw}->{Co}", yv.view(M, Co), ref, BF16_TOL)
+        check(f"k64 {name} vs 128-row {M_hw}->{Co}", yv, yo, BF16_TOL)
+        assert pv.shape[0] == (M + 127) // 128
+        for c in range(pv.shape[0]):
+            blk = ref[c * 128:min(M, (c + 1) * 128)]
+            K = pv[c, 2].double()
+            assert float((K - blk[0]).abs().max()) <= BF16_TOL * float(ref.abs().max()), "shift = the chunk's first row"
+            d = blk - K
+            assert float((pv[c, 0].double() - d.sum(0)).abs().max()) <= 1e-3 * max(float(d.abs().sum(0).max()), 1e-6), f"{name} chunk {c} S1"
+            assert float((pv[c, 1].double() - (d * d).sum(0)).abs().max()) <= 1e-3 * max(float((d * d).sum(0).max()), 1e-6), f"{name} chunk {c} S2"
+
+
 W3_CASES = [
     # N, Ci, H, W, Co, k, s, p : both channel counts multiples of 256 (the v3 weight-gradient core's domain); pixel counts that
     # are not multiples of the 32-pixel unit, fewer units than the 3-deep prefetch, padding taps, stride 2 (odd sizes: the last
