@@ -919,7 +919,7 @@ int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat
   }
   if (gather_bf16_v3_ok(g, false)) return launch_gather_bf16_v3(x, w, y, g, false, st);      // K-heavy layers: 256x256 LDS-DMA core
   if (Hi == Ho && Wi == Wo && !((uintptr_t)y & 15) && conv1x1_k64_ok(N, Hi, Wi, Ci, Co, KH, KW, stride, pad))
-    return launch_conv1x1_k64(x, nullptr, w, y, N, Hi, Wi, Co, stat_part, st);                    // 64 -> 128..512 1x1: streaming kernel
+    return launch_conv1x1_k64(x, nullptr, w, y, N, Hi, Wi, Ci, Co, stat_part, st);                    // 64 -> 128..512 1x1: streaming kernel
   if (Hi == Ho && Wi == Wo && !((uintptr_t)y & 15) && conv3x3_c64_ok(N, Hi, Wi, Ci, Co, KH, KW, stride, pad))
     return launch_conv3x3_c64(x, w, 0, y, N, Hi, Wi, stat_part, nullptr, nullptr, nullptr, st);   // 64 -> 64 3x3: weight-stationary kernel
   if (Co <= 64) return launch_gather_bf16<64, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
@@ -1108,7 +1108,7 @@ int edrl_conv2d_nhwc_fwd_bnin_stats_bf16(const void* x, const float* in_fcoef, c
   g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
   g.stat_part = stat_part; g.stat_shift = nullptr;
   if (Hi == Ho && Wi == Wo && !((uintptr_t)y & 15) && conv1x1_k64_ok(N, Hi, Wi, Ci, Co, KH, KW, stride, pad))
-    return launch_conv1x1_k64(x, in_fcoef, w, y, N, Hi, Wi, Co, stat_part, st);
+    return launch_conv1x1_k64(x, in_fcoef, w, y, N, Hi, Wi, Ci, Co, stat_part, st);
   GatherFuse F;
   memset(&F, 0, sizeof(F));
   F.acoef = in_fcoef;

@@ -301,23 +301,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_bf16_kernel(const __bf16* 
 // then NC/64 passes of 2 x 32 MFMAs over the same fragments, each with the c64 epilogue (permlane16_swap -> 16-byte stores, BatchNorm
 // chunk partials of its 64 channels from the fp32 accumulators).  No barrier, no LDS traffic for the pixels; the HBM queue is kept
 // full by the 8 independent waves per CU.
-template <int ATR>
-__global__ __launch_bounds__(512, 2) void conv1x1_k64_bf16_kernel(const __bf16* __restrict__ src, const __bf16* __restrict__ w,
-                                                                  __bf16* __restrict__ dst, int M, int NC, int nchunks,
-                                                                  const float* __restrict__ fcoef, float* __restrict__ stat_part) {
+// KS = K / 32: 2 (64 input channels: 8 waves, two per SIMD) or 4 (128 input channels, `layer2.*.conv3`: the chunk's fragments are 128
+// registers, so 4 waves per workgroup, one per SIMD with the whole register file; the weights of 512 x 128 fill 128 KiB of LDS).
+template <int ATR, int KS>
+__global__ __launch_bounds__(KS == 2 ? 512 : 256, KS == 2 ? 2 : 1) void conv1x1_k64_bf16_kernel(
+    const __bf16* __restrict__ src, const __bf16* __restrict__ w, __bf16* __restrict__ dst, int M, int NC, int nchunks,
+    const float* __restrict__ fcoef, float* __restrict__ stat_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KC = 32 * KS;                    // input channels
+  constexpr int NW = KS == 2 ? 8 : 4;            // waves per workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nct = NC >> 4;
-  // weights [NC][64] -> LDS fragment order [ks 2][channel tile][lane]: lane l = (channel 16 ct + (l&15), k 32 ks + 8 (l>>4) .. +7)
-  for (int idx = tid; idx < 2 * nct * 64; idx += 512) {
+  // weights [NC][KC] -> LDS fragment order [ks][channel tile][lane]: lane l = (channel 16 ct + (l&15), k 32 ks + 8 (l>>4) .. +7)
+  for (int idx = tid; idx < KS * nct * 64; idx += NW * 64) {
     const int l = idx & 63, ct = (idx >> 6) % nct, ks = (idx >> 6) / nct;
     *reinterpret_cast<c64_bf16x8*>(smem + idx * 16) =
-        *reinterpret_cast<const c64_bf16x8*>(w + (long)(16 * ct + (l & 15)) * 64 + 32 * ks + 8 * (l >> 4));
+        *reinterpret_cast<const c64_bf16x8*>(w + (long)(16 * ct + (l & 15)) * KC + 32 * ks + 8 * (l >> 4));
   }
-  float* tco = reinterpret_cast<float*>(smem + NC * 128);       // ATR 1: [scale 64][shift2 64] of the input BatchNorm, behind the weights
+  float* tco = reinterpret_cast<float*>(smem + NC * KC * 2);    // ATR 1: [scale KC][shift2 KC] of the input BatchNorm, behind the weights
   if constexpr (ATR == 1) {
-    if (tid < 128) tco[tid] = fcoef[(tid < 64 ? 2 : 4) * 64 + (tid & 63)];
+    if (tid < 2 * KC) tco[tid] = fcoef[(tid < KC ? 2 : 4) * KC + (tid % KC)];
   }
   __syncthreads();
   const int pl = lane & 15, gq = lane >> 4;
@@ -331,25 +335,25 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bf16_kernel(const __bf16* 
     return x;
   };
   const unsigned char* wl = smem + lane * 16;
-  for (int chunk = blockIdx.x * 8 + wave; chunk < nchunks; chunk += gridDim.x * 8) {
+  for (int chunk = blockIdx.x * NW + wave; chunk < nchunks; chunk += gridDim.x * NW) {
     const int m0 = chunk * 128;
-    // ---- the chunk's pixel fragments: 8 column tiles x 2 K steps, 16 bytes per lane each
-    c64_bf16x8 a[8][2];
+    // ---- the chunk's pixel fragments: 8 column tiles x KS K steps, 16 bytes per lane each
+    c64_bf16x8 a[8][KS];
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {
       const int m = m0 + 16 * pt + pl;
-      const long mo = (long)(m < M ? m : M - 1) * 64;            // (rows past the end: a valid address, results never stored)
+      const long mo = (long)(m < M ? m : M - 1) * KC;            // (rows past the end: a valid address, results never stored)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a[pt][ks] = *reinterpret_cast<const c64_bf16x8*>(src + mo + 32 * ks + 8 * gq);
+      for (int ks = 0; ks < KS; ++ks) a[pt][ks] = *reinterpret_cast<const c64_bf16x8*>(src + mo + 32 * ks + 8 * gq);
     }
     if constexpr (ATR == 1) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         f32x4 tsc[2], tsh[2];            // scale / shift2 of this lane's input channels 32 ks + 8 gq + 4 h .. +3 (from LDS: no registers held)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           tsc[h] = *reinterpret_cast<const f32x4*>(tco + 32 * ks + 8 * gq + 4 * h);
-          tsh[h] = *reinterpret_cast<const f32x4*>(tco + 64 + 32 * ks + 8 * gq + 4 * h);
+          tsh[h] = *reinterpret_cast<const f32x4*>(tco + KC + 32 * ks + 8 * gq + 4 * h);
         }
 #pragma unroll
         for (int pt = 0; pt < 8; ++pt) {
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bf16_kernel(const __bf16* 
 #pragma unroll
           for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
           c64_bf16x8 wf[4];
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) wf[ct] = *reinterpret_cast<const c64_bf16x8*>(wl + ((ks * nct + 4 * q + ct) << 10));
@@ -446,33 +450,38 @@ bool conv1x1_k64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int str
   const char* env = getenv("EDRL_BF16_K64");           // 0 off, 1 auto (default), 2 wherever the geometry allows (read per call)
   const int mode = env ? atoi(env) : 1;
   if (mode == 0) return false;
-  if (Ci != 64 || (Co % 64) || Co < 64 || Co > 512 || KH != 1 || KW != 1 || stride != 1 || pad != 0 || N <= 0) return false;
+  if ((Ci != 64 && Ci != 128) || (Co % 64) || Co < 64 || Co > 512 || KH != 1 || KW != 1 || stride != 1 || pad != 0 || N <= 0) return false;
   const long M = (long)N * H * W;
   if (M > 0x7fffff00L) return false;
   return mode == 2 || (M >= 128L * 2048 && Co >= 128);     // streaming layers only: below that the 128-row kernel's grid fills the chip
 }
 
-// y [M][Co] = conv1x1(x [M][64] (ATR: relu(x*scale + shift2) with in_fcoef [5][64]), w [Co][64]); stat_part optional.
-int launch_conv1x1_k64(const void* x, const float* in_fcoef, const void* w, void* y, int N, int H, int W, int Co, float* stat_part,
-                       hipStream_t st) {
+template <int ATR, int KS>
+static void launch_k64_impl(const void* x, const float* in_fcoef, const void* w, void* y, long M, int Co, int nchunks, float* stat_part,
+                            hipStream_t st) {
+  constexpr int NW = KS == 2 ? 8 : 4;
+  int grid = (nchunks + NW - 1) / NW;
+  if (grid > 256) grid = 256;
+  const int lds = Co * 32 * KS * 2 + 1024;
+  auto kern = conv1x1_k64_bf16_kernel<ATR, KS>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * KS * 2 + 1024); attr = true; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, (const __bf16*)x, (const __bf16*)w, (__bf16*)y, (int)M, Co, nchunks,
+                     in_fcoef, stat_part);
+}
+
+// y [M][Co] = conv1x1(x [M][Ci] (ATR: relu(x*scale + shift2) with in_fcoef [5][Ci]), w [Co][Ci]), Ci = 64 | 128; stat_part optional.
+int launch_conv1x1_k64(const void* x, const float* in_fcoef, const void* w, void* y, int N, int H, int W, int Ci, int Co,
+                       float* stat_part, hipStream_t st) {
   const long M = (long)N * H * W;
   const int nchunks = (int)((M + 127) / 128);
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return EDRL_EINVAL;
-  int grid = (nchunks + 7) / 8;
-  if (grid > 256) grid = 256;
-  const int lds = Co * 64 * 2 + 512;
-  if (in_fcoef) {
-    auto kern = conv1x1_k64_bf16_kernel<1>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 2 + 512); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const __bf16*)x, (const __bf16*)w, (__bf16*)y, (int)M, Co, nchunks,
-                       in_fcoef, stat_part);
+  if (Ci == 64) {
+    if (in_fcoef) launch_k64_impl<1, 2>(x, in_fcoef, w, y, M, Co, nchunks, stat_part, st);
+    else launch_k64_impl<0, 2>(x, in_fcoef, w, y, M, Co, nchunks, stat_part, st);
   } else {
-    auto kern = conv1x1_k64_bf16_kernel<0>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 2 + 512); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const __bf16*)x, (const __bf16*)w, (__bf16*)y, (int)M, Co, nchunks,
-                       (const float*)nullptr, stat_part);
+    if (in_fcoef) launch_k64_impl<1, 4>(x, in_fcoef, w, y, M, Co, nchunks, stat_part, st);
+    else launch_k64_impl<0, 4>(x, in_fcoef, w, y, M, Co, nchunks, stat_part, st);
   }
   EDRL_LAUNCH_CHECK();
   return 0;

@@ -181,16 +181,16 @@ def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, monkey
         assert float((ev[c, 1].double() - (gb * xb).sum(0)).abs().max()) <= 1e-3 * max(float((gb * xb).abs().sum(0).max()), 1e-6), f"chunk {c} sum g*x"
 
 
-@pytest.mark.parametrize("M_hw,Co", [((2, 14, 14), 256), ((3, 9, 7), 128), ((1, 5, 5), 64), ((5, 16, 13), 512)])
-def test_conv1x1_k64_streaming_kernel_vs_fp64_and_128row_kernel(edrl, dev, M_hw, Co, monkeypatch):
-    """The streaming 64 -> Co 1x1 kernel (csrc/conv_c64_bf16.hip: weights in LDS, a wave owns 128 pixels x all output channels, pixel
+@pytest.mark.parametrize("M_hw,C,Co", [((2, 14, 14), 64, 256), ((3, 9, 7), 64, 128), ((1, 5, 5), 64, 64), ((5, 16, 13), 64, 512),
+                                       ((2, 14, 14), 128, 512), ((3, 9, 7), 128, 128), ((5, 16, 13), 128, 256)])
+def test_conv1x1_k64_streaming_kernel_vs_fp64_and_128row_kernel(edrl, dev, M_hw, C, Co, monkeypatch):
+    """The streaming 64 | 128 -> Co 1x1 kernel (csrc/conv_c64_bf16.hip: weights in LDS, a wave owns 128 pixels x all output channels, pixel
     fragments loaded and transformed in registers once per chunk), forced on (EDRL_BF16_K64=2) at small sizes (pixel counts off every
     tile size, one case below a single chunk): plain forward with BatchNorm chunk partials and the fused form (BatchNorm + ReLU of the
     input in the operand), against fp64 of the same bf16 operands (one bf16 ulp; partials 1e-3 of their scale) and against the
     128-row kernel (EDRL_BF16_K64=0), which forms the same transformed operand (same fp32 arithmetic, one rounding)."""
     ops, L = edrl.ops, edrl._lib
     N, H, W = M_hw
-    C = 64
     g = torch.Generator().manual_seed(43)
     x = torch.randn(N, H, W, C, generator=g).bfloat16()
     w = (torch.randn(Co, 1, 1, C, generator=g) * 0.2).bfloat16()
