@@ -126,6 +126,9 @@ BF16_GEOMS = [  # N, H, W, Ci, Co, k, stride, pad : channel counts the 256x256 L
     (14, 7, 7, 256, 256, 1, 1, 0), (2, 6, 6, 512, 512, 1, 2, 0),
     # the 128-row / 128x128 kernels' domain: narrow layers, channel counts that end inside a tile
     (2, 9, 9, 64, 64, 3, 1, 1), (3, 7, 5, 64, 200, 1, 1, 0), (2, 8, 8, 96, 64, 3, 2, 1),
+    # the weight-stationary kernels' domain (conv_c64_bf16.hip): 64 -> 64 3x3 (above), 64 -> 256 and 128 -> 512 1x1; pixel counts off
+    # their 16 / 64 / 128-pixel granularities
+    (3, 7, 5, 64, 256, 1, 1, 0), (2, 6, 6, 128, 512, 1, 1, 0), (1, 11, 13, 64, 64, 3, 1, 1),
 ]
 
 
@@ -133,13 +136,16 @@ BF16_GEOMS = [  # N, H, W, Ci, Co, k, stride, pad : channel counts the 256x256 L
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", BF16_GEOMS)
 def test_bf16_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, Co, k, s, p, mode, monkeypatch):
     """The same guard-band check for the bf16 launchers: forward (+ BatchNorm partials), data gradient (write / accumulate), weight
-    gradient incl. its split-K workspace -- once on the 128-row / 128x128 kernels (mode 0) and once with the 256x256 LDS-DMA cores
-    forced wherever the geometry allows (mode 2: conv_bf16_v3.hip, conv_wgrad_bf16_v3.hip; their DMA pieces for rows / taps outside
-    the tensors are out-of-range buffer offsets and must neither fault nor leak into the outputs)."""
+    gradient incl. its split-K workspace -- once on the 128-row / 128x128 kernels (mode 0) and once with the 256x256 LDS-DMA cores and
+    the weight-stationary kernels forced wherever the geometry allows (mode 2: conv_bf16_v3.hip, conv_wgrad_bf16_v3.hip,
+    conv_c64_bf16.hip; their loads for rows / taps outside the tensors are out-of-range buffer offsets or clamped rows and must
+    neither fault nor leak into the outputs)."""
     ops, L = edrl.ops, edrl._lib
     P = L.ptr
     monkeypatch.setenv("EDRL_BF16_V3", mode)
     monkeypatch.setenv("EDRL_BF16_WGRAD_V3", mode)
+    monkeypatch.setenv("EDRL_BF16_C64", mode)
+    monkeypatch.setenv("EDRL_BF16_K64", mode)
     bf = torch.bfloat16
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + Co)
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
