@@ -220,7 +220,8 @@ def main():
                 res["roofline"] = {
                     "kernel": ("conv_gather_bf16 family (implicit-GEMM conv fwd+dgrad): conv_gather_bf16_v3_kernel (256x256 LDS-DMA core, "
                                "v_mfma_f32_16x16x32_bf16: K-heavy layers) + conv_gather_bf16_kernel (128-row, v_mfma_f32_32x32x16_bf16: "
-                               "HBM-bound and fused-BatchNorm layers)"
+                               "HBM-bound and fused-BatchNorm layers) + conv3x3_c64_bf16_kernel / conv1x1_k64_bf16_kernel (weight-stationary: "
+                               "64-channel 3x3 and expanding 1x1 layers of stages 1-2)"
                                if enc_dtype == "bf16" else
                                "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)"),
                     "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": peak,
