@@ -79,10 +79,16 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
   const int ohw = g.OHs * g.OWs;
   const int n_first = (int)(m0 / ohw);
   int pb[2], hw[2];
+  // 1x1 / stride 1 / pad 0 (forward and data gradient alike): source pixel = output row, no (n, oh, ow) decode -- the two 64-bit
+  // divisions per thread are a fifth of the prologue of a short-K tile
+  const bool lin = g.KH == 1 && g.KW == 1 && g.pad == 0 && g.stride == 1 && g.step == 1 && g.SH == g.OHs && g.SW == g.OWs;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const long m = m0 + srow + 128 * j;
-    if (m < g.M) {
+    if (lin) {
+      pb[j] = m < g.M ? (int)(m - (long)n_first * ohw) : -1;
+      hw[j] = (16384 << 16) | 16384;
+    } else if (m < g.M) {
       const int n = (int)(m / ohw);
       const int rem = (int)(m - (long)n * ohw);
       const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
