@@ -33,8 +33,10 @@ typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
 //   EPI 1: the computed tile is the gradient of a BatchNorm(+ReLU) output: masked (sign bytes or decision re-derived from the
 //          raw tensor), stored as bf16, and (sum g, sum g*x) of the UNROUNDED fp32 values go to ep_part.
 //   MASK : padding taps / masked rows must read as exactly 0 after the transform (false for 1x1 / pad-0 layers).
-// OCC4: compiled for 4 workgroups per CU (128 VGPRs, 4 x 40 KiB of LDS): the forward with the operand transform (ATR 1), whose
-// short-K layers are latency-bound at 3.
+// OCC4: compiled for 4 workgroups per CU (128 VGPRs, 4 x 40 KiB of LDS): the forward kernels (plain and with the operand transform,
+// ATR 1): 8 MFMAs per wave and K tile cannot hide a global load, so the K loop runs at about one memory latency per tile and a
+// fourth workgroup per CU is worth more than the 4 spilled registers (a second register stage for the loads was tried instead:
+// 46 spilled registers at the 168-register budget, 2x slower).
 template <int BN, bool DGRAD, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true, bool OCC4 = false>
 __global__ __launch_bounds__(256, OCC4 ? 4 : 3) void conv_gather_bf16_kernel(const __bf16* __restrict__ src,
                                                                   const __bf16* __restrict__ wm,
@@ -483,9 +485,10 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   GatherGeom gm = g;
   { const char* e = getenv("EDRL_BF16_EPI_VW4"); if (e && e[0] == '1') gm.flags |= GF_EPI_VW4; }
   { const char* e = getenv("EDRL_BF16_KTAIL"); if (e && e[0] == '1') gm.flags |= GF_KTAIL; }     // (A/B) keep the past-the-end load round
-  if constexpr (ATR == 1 && EPI == 0 && !DGRAD) {
-    const char* e = getenv("EDRL_BF16_FWD_OCC4");            // (A/B switch, read per call)
-    if (!(e && e[0] == '0')) {
+  if constexpr ((ATR == 1 || (ATR == 0 && BUF)) && EPI == 0 && !DGRAD) {
+    const char* e = getenv("EDRL_BF16_FWD_OCC4");            // (A/B switches, read per call)
+    const char* e0 = getenv("EDRL_BF16_PLAIN_OCC4");         // plain operands: l3 256->1024 0.53 -> 0.48 ms, l4 512->2048 0.39 -> 0.35 ms
+    if (!(e && e[0] == '0') && (ATR == 1 || !(e0 && e0[0] == '0'))) {
       auto k4 = conv_gather_bf16_kernel<BN, DGRAD, BUF, ATR, EPI, MASK, true>;
       static bool attr4 = false;
       if (!attr4) { (void)hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr4 = true; }
