@@ -10,8 +10,11 @@ forward(high view) -> MK_MMD -> backward -> (DP gradient all-reduce) -> Adam.ste
 BASELINE.json configs[1] (C1): per-GPU batch 32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32.
 At N>1 it is configs[3] (C3): the same shapes at per-GPU batch 64 (global 512 at N=8), data parallel, with the residual
 blocks' outputs rebuilt in backward so that the fp32 activations of 2 x 64 x 33 images fit one GPU's 288 GB.  The default
-N=1 line also times that C3 per-GPU workload on the one GPU (`scale_anchor`), so 1 -> N efficiency has an equal-work anchor.
-Prints ONE JSON line on rank 0.
+N=1 line also times that C3 per-GPU workload on the one GPU (`scale_anchor`), so 1 -> N efficiency has an equal-work anchor,
+and the two bf16 configurations: `bf16_leg` (C2 = BASELINE.json configs[2], 5 timed steps, its own roofline block) and `c4_leg`
+(C4 = configs[4] per-GPU shape, 3 timed steps).  `value` stays C1.  At N > 1 the line carries `grad_exchange` (bucket count,
+bytes, when the first all-reduce was issued relative to backward, how long the optimiser waited for the exchange) and the
+per-rank step times.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -46,6 +49,111 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense, 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 
 
+PMC_FAMILIES = {   # bench timer key -> kernel families of scripts/pmc_traffic.py whose launches it brackets
+    "conv_gather": ("conv_gather",),                 # (rocprofv3's rows also hold the head's Linear layers: bench key linear_gather)
+    "conv_gather_bf16": ("conv_gather_bf16_v3", "conv_gather_bf16", "conv3x3_c64_bf16", "conv1x1_k64_bf16"),
+}
+
+
+def pmc_traffic(cfg, desc, dom_key):
+    """HBM bytes of the dominant kernel family PER STEP from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/pmc_traffic_<cfg>.json, scripts/gpu_pmc_cfg.sh: FETCH_SIZE x 1024 x 2 for the gfx950 half-count, WRITE_SIZE x 1024);
+    None when no such file exists for this workload."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{cfg.lower()}.json")))
+    except (OSError, ValueError):
+        return None
+    if pm.get("workload") != desc:
+        return None
+    steps = float(pm.get("profiled_steps", 2))       # the passes profile 1 warm-up + 1 timed step
+    tot, launches = 0.0, 0
+    for fam in PMC_FAMILIES.get(dom_key, ()):
+        k = pm.get("kernels", {}).get(fam)
+        if k:
+            tot += k["hbm_bytes_per_launch"] * k["launches"]
+            launches += k["launches"]
+    if launches == 0:
+        return None
+    return {"bytes_per_step": tot / steps, "launches_per_step": launches / steps,
+            "source": f"static: profiles/pmc_traffic_{cfg.lower()}.json -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same "
+                      "command, collected separately (not measured in this run)"}
+
+
+def roofline_blocks(timer, enc_dtype, dt, steps, cfg, desc):
+    """(roofline, kernels) of one timed region from the HIP-event kernel timer."""
+    ks = timer.summary()
+    dom_key = "conv_gather_bf16" if enc_dtype == "bf16" else "conv_gather"
+    dom = ks.get(dom_key)
+    roof = None
+    if dom:
+        avg_ms = dom["ms"] / dom["launches"]
+        peak = PEAK_BF16_MFMA_TFLOPS if enc_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        # algorithmic bytes per step of everything rocprofv3 files under this family: the head's Linear layers run the same kernels
+        lin = ks.get("linear_gather") if enc_dtype != "bf16" else None
+        alg_step = (dom.get("bytes", 0.0) + (lin.get("bytes", 0.0) if lin else 0.0)) / steps
+        roof = {
+            "kernel": ("conv_gather_bf16 family (implicit-GEMM conv fwd+dgrad): conv_gather_bf16_v3_kernel (256x256 LDS-DMA core, "
+                       "v_mfma_f32_16x16x32_bf16: K-heavy layers) + conv_gather_bf16_kernel (128-row, v_mfma_f32_32x32x16_bf16: "
+                       "HBM-bound and fused-BatchNorm layers) + conv3x3_c64_bf16_kernel / conv1x1_k64_bf16_kernel (weight-stationary: "
+                       "64-channel 3x3 and expanding 1x1 layers of stages 1-2)"
+                       if enc_dtype == "bf16" else
+                       "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)"),
+            "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
+            "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
+            "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+            "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"]),
+            "algorithmic_flop_per_byte": round(dom["flops"] / dom["bytes"], 2) if dom.get("bytes") else None,
+            "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
+            # each call priced by whichever of ITS algorithmic flops (MFMA peak) or bytes (8 TB/s) binds: the fused
+            # BatchNorm layers of stages 1-2 read two K-wide operand tensors and sit on the HBM side of the ridge
+            "per_call_bound": {"speed_of_light_ms": round(dom["bound_ms"], 3), "measured_ms": round(dom["ms"], 3),
+                               "frac": round(dom["bound_ms"] / dom["ms"], 4)},
+            # the same launches split by the resource that binds each call: MFMA-bound calls against the MFMA peak,
+            # HBM-bound calls (algorithmic bytes / 8 TB/s > flops / peak) in GB/s against the HBM spec
+            "by_bound": {
+                "mfma": {"calls": dom["by_bound"]["mfma"]["calls"], "ms": round(dom["by_bound"]["mfma"]["ms"], 3),
+                         "tflops": round(dom["by_bound"]["mfma"]["tflops"], 3),
+                         "frac": round(dom["by_bound"]["mfma"]["tflops"] / peak, 4)},
+                "hbm": {"calls": dom["by_bound"]["hbm"]["calls"], "ms": round(dom["by_bound"]["hbm"]["ms"], 3),
+                        "GBps": round(dom["by_bound"]["hbm"]["GBps"], 1),
+                        "frac_of_8TBps": round(dom["by_bound"]["hbm"]["GBps"] / 8000.0, 4)}} if "by_bound" in dom else None,
+            "launch_unit": "kernel launches as rocprofv3 counts them (a stride-2 data-gradient call issues one kernel "
+                           "per non-empty parity class; the HIP events bracket the call); rocprofv3's conv_gather_* rows are these "
+                           "launches plus the head's Linear layers, which run the same kernels (key linear_gather below)",
+        }
+        # measured HBM traffic against algorithmic bytes on ONE denominator (the step); `traffic` (per launch, the contract's
+        # field) = measured bytes per step / the launches THIS line counts per step
+        pm = pmc_traffic(cfg, desc, dom_key)
+        roof["per_step"] = {"algorithmic_bytes": round(alg_step), "measured_hbm_bytes": None, "measured_over_algorithmic": None,
+                            "launches": dom["launches"] / steps,
+                            "note": "algorithmic bytes: this family's launches" + (" + the head's Linear layers (same kernels, same "
+                                    "rocprofv3 rows)" if lin else "")}
+        if pm:
+            roof["traffic"] = round(pm["bytes_per_step"] / (dom["launches"] / steps))
+            roof["traffic_source"] = pm["source"]
+            roof["per_step"].update(measured_hbm_bytes=round(pm["bytes_per_step"]),
+                                    measured_over_algorithmic=round(pm["bytes_per_step"] / alg_step, 3) if alg_step else None,
+                                    rocprofv3_launches=pm["launches_per_step"])
+        if enc_dtype == "bf16":
+            roof["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
+                            "HBM-bound (50-250 FLOP/B against a ~450 FLOP/B ridge), only the 3x3 layers of "
+                            "stages 2-4 and the 1x1 layers with >= 1024 input channels are MFMA-bound: "
+                            "per_call_bound / by_bound price each call by its own binding resource")
+    kern = {}
+    for k, v in ks.items():
+        e = {"launches": v["launches"], "calls": v["calls"], "ms_total": round(v["ms"], 3)}
+        if "GBps" in v and v["flops"] == 0:      # HBM-bound passes: algorithmic bytes / HIP-event time against the 8 TB/s HBM3E spec
+            e.update(bound="hbm", GBps=round(v["GBps"], 1), frac_of_8TBps=round(v["GBps"] / 8000.0, 4),
+                     algorithmic_bytes=v["bytes"])
+        else:
+            e.update(bound="mfma", tflops=round(v["tflops"], 3), per_call_bound_frac=round(v["bound_ms"] / v["ms"], 4) if v["ms"] > 0 else None)
+            if v.get("bytes"):
+                e.update(algorithmic_GBps=round(v["GBps"], 1), algorithmic_bytes=v["bytes"])
+        kern[k] = e
+    return roof, kern
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,8 +168,10 @@ def main():
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra timed region with the two views overlapped")
     ap.add_argument("--no-recompute-leg", action="store_true", help="skip the extra timed region with args.activation_recompute")
     ap.add_argument("--no-anchor-leg", action="store_true", help="skip the N = 1 timing of the C3 per-GPU workload (scale_anchor)")
+    ap.add_argument("--no-bf16-legs", action="store_true", help="skip the C2 / C4 legs of the default N = 1 line (bf16_leg, c4_leg)")
     a = ap.parse_args()
 
+    import gc
     import torch
     import torch.distributed as dist
     import edrl_amd
@@ -83,25 +193,35 @@ def main():
 
     if a.config is None:
         a.config = "C1" if a.gpus == 1 else "C3"
-    B, depth, HW, S, enc_dtype, desc = CONFIGS[a.config]
-    recompute = a.recompute or a.config in RECOMPUTE
-    if a.batch:
-        B = a.batch
-        desc = desc.replace(f"B={CONFIGS[a.config][0]}/GPU", f"B={B}/GPU (override)")
-    # strict_labels keeps its default ("deferred": violation flag on the device, raised by raise_on_bad_labels() below)
-    args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, activation_recompute=recompute,
-                                 encoder_dtype=enc_dtype, oct_encoder="3d" if a.config == "C1-3D" else "slices", oct3d_depth=18)
-    torch.manual_seed(0)
-    model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
-    edrl_amd.broadcast_parameters(model)
-    # the reference's optim.Adam(lr, weight_decay=1e-6) (fusion_train.py:747) as one multi-tensor launch; --torch-adam: stock
-    opt = (torch.optim.Adam if a.torch_adam else edrl_amd.FusedAdam)(model.parameters(), lr=1e-4, weight_decay=1e-6)
-    sync = edrl_amd.GradSync(model) if world > 1 else None
-    data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank, drop_oct_high=(a.config == "C4"))
-    run = {"model": model, "opt": opt, "data": data, "y": y}     # what step() drives (the scale-anchor leg swaps it)
+    default_line = world == 1 and a.config == "C1" and not a.batch
+    run = {}     # what step() drives (the extra legs swap it)
+
+    def build(cfg, batch=0, recompute=None):
+        """Model + optimiser + resident synthetic batch of one configuration -> its description record."""
+        B, depth, HW, S, enc_dtype, desc = CONFIGS[cfg]
+        rec = (a.recompute or cfg in RECOMPUTE) if recompute is None else recompute
+        if batch:
+            desc = desc.replace(f"B={B}/GPU", f"B={batch}/GPU (override)")
+            B = batch
+        # strict_labels keeps its default ("deferred": violation flag on the device, raised by raise_on_bad_labels() below)
+        args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, activation_recompute=rec,
+                                     encoder_dtype=enc_dtype, oct_encoder="3d" if cfg == "C1-3D" else "slices", oct3d_depth=18)
+        torch.manual_seed(0)
+        model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
+        edrl_amd.broadcast_parameters(model)
+        # the reference's optim.Adam(lr, weight_decay=1e-6) (fusion_train.py:747) as one multi-tensor launch; --torch-adam: stock
+        opt = (torch.optim.Adam if a.torch_adam else edrl_amd.FusedAdam)(model.parameters(), lr=1e-4, weight_decay=1e-6)
+        data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank, drop_oct_high=(cfg == "C4"))
+        run.clear()
+        run.update(model=model, opt=opt, data=data, y=y, sync=edrl_amd.GradSync(model) if world > 1 else None)
+        return dict(cfg=cfg, B=B, depth=depth, HW=HW, S=S, enc_dtype=enc_dtype, desc=desc, recompute=rec)
+
+    def drop():
+        run.clear()
+        gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
 
     def step():
-        return edrl_amd.train_step(run["model"], run["opt"], run["data"], run["y"], grad_sync=sync)
+        return edrl_amd.train_step(run["model"], run["opt"], run["data"], run["y"], grad_sync=run["sync"])
 
     def timed_region(steps, with_timer):
         timer = None
@@ -116,17 +236,38 @@ def main():
         for _ in range(steps):
             o = step()
         torch.cuda.synchronize()
+        dt_local = time.perf_counter() - t0          # this rank's own time (before it waits for the others)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         edrl_amd.ops.set_timer(None)
+        per_rank = None
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
-        return dt, timer, o
+            tl = torch.zeros(world, device=dev, dtype=torch.float64)
+            tl[rank] = dt_local
+            dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+            per_rank = [round(x / steps * 1e3, 3) for x in tl.tolist()]
+        return dt, timer, o, per_rank
 
+    def overlap_leg(B, steps):
+        """Not `value`: the same steps with the two views' encoder passes on two HIP streams (edrl_amd.set_view_overlap).  Kernels
+        of the two passes then share the GPU, so per-kernel durations -- and a per-kernel roofline -- stop being meaningful there."""
+        edrl_amd.set_view_overlap(True)
+        step(); torch.cuda.synchronize()
+        dt2, _, _, _ = timed_region(steps, False)
+        edrl_amd.set_view_overlap(False)
+        return {"switch": "EDRL_VIEW_STREAM=1 / edrl_amd.set_view_overlap(True)", "value": round(B * world * steps / dt2, 3),
+                "unit": "images/s", "ms_per_step": round(dt2 / steps * 1e3, 3), "steps": steps,
+                "note": "two views' encoder passes on two HIP streams (MFMA convs of one overlap HBM-bound BatchNorm of the other); "
+                        "identical losses/gradients/running statistics; per-kernel timing not taken in this leg"}
+
+    want_overlap = world == 1 and not a.no_overlap_leg and os.environ.get("EDRL_VIEW_STREAM", "0") != "1"
+    c = build(a.config, a.batch)
+    B, depth, HW, S, enc_dtype, desc, recompute = c["B"], c["depth"], c["HW"], c["S"], c["enc_dtype"], c["desc"], c["recompute"]
     if rank == 0:
         print(f"[bench] {desc}: model ready, warm-up {a.warmup} step(s)", file=sys.stderr, flush=True)
     for _ in range(a.warmup):
@@ -134,25 +275,40 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] timing {a.steps} step(s)", file=sys.stderr, flush=True)
-    dt, timer, out = timed_region(a.steps, True)
-    # Extra leg (not `value`): the same K steps with the two views' encoder passes on two HIP streams
-    # (edrl_amd.set_view_overlap).  Kernels of the two passes then share the GPU, so per-kernel durations -- and with
-    # them a per-kernel roofline -- stop being meaningful there; the primary region above runs them one at a time.
-    overlap = None
-    if world == 1 and not a.no_overlap_leg and os.environ.get("EDRL_VIEW_STREAM", "0") != "1":
-        edrl_amd.set_view_overlap(True)
-        step(); torch.cuda.synchronize()
-        dt2, _, _ = timed_region(a.steps, False)
-        edrl_amd.set_view_overlap(False)
-        overlap = {"switch": "EDRL_VIEW_STREAM=1 / edrl_amd.set_view_overlap(True)", "value": round(B * world * a.steps / dt2, 3),
-                   "unit": "images/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3), "steps": a.steps,
-                   "note": "two views' encoder passes on two HIP streams (MFMA convs of one overlap HBM-bound BatchNorm of the other); "
-                           "identical losses/gradients/running statistics; per-kernel timing not taken in this leg"}
+    dt, timer, out, per_rank = timed_region(a.steps, True)
+    overlap = overlap_leg(B, a.steps) if want_overlap else None
     loss = out["loss"].item()
+    model = run["model"]
     model.raise_on_bad_labels()
     model.raise_on_nonfinite()            # the fused BatchNorm+ReLU loads map NaN to 0: divergence shows in the running statistics
     assert loss == loss, "NaN loss"
     peak_primary = torch.cuda.max_memory_allocated()
+
+    # N > 1: what the gradient exchange did, from two extra steps with GradSync's diagnostics on (a synchronize per step, so
+    # outside the timed region): bucket count and bytes, when the first all-reduce was ISSUED relative to backward's start / end
+    # (host clock and compute-stream events), and how long the optimiser's stream waited for the communication stream.
+    exchange = None
+    if world > 1:
+        sync = run["sync"]
+        sync.enable_diagnostics(True)
+        reps = []
+        for _ in range(2):
+            step(); torch.cuda.synchronize()
+            reps.append(sync.step_report())
+        sync.enable_diagnostics(False)
+        mine = reps[-1] or {}
+        exposed = torch.tensor([mine.get("comm_exposed_ms", -1.0), mine.get("backward_gpu_ms", -1.0),
+                                (mine.get("launch_gpu_ms_after_backward_start") or [-1.0])[0]], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(exposed) for _ in range(world)]
+        dist.all_gather(allr, exposed)
+        exchange = dict(mine, backend=backend, bucket_mb=sync.bucket_bytes >> 20,
+                        per_rank={"comm_exposed_ms": [round(t[0].item(), 3) for t in allr],
+                                  "backward_gpu_ms": [round(t[1].item(), 3) for t in allr],
+                                  "first_launch_gpu_ms_after_backward_start": [round(t[2].item(), 3) for t in allr]},
+                        note="rank 0's last diagnostic step (lists: one entry per bucket in launch order) + per-rank summaries; "
+                             "comm_exposed_ms = how long finish() had the compute stream wait for the communication stream, i.e. the "
+                             "part of the all-reduce that backward did not hide")
+
     # Extra leg (not `value`): the same steps with args.activation_recompute (block outputs and their ReLU sign bytes rebuilt in
     # backward by the forward's own kernel, bit-identical gradients) -- the memory/throughput trade the C3 configuration runs with.
     recompute_leg = None
@@ -163,7 +319,7 @@ def main():
         torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
         step(); torch.cuda.synchronize()
         k3 = min(a.steps, 4)
-        dt3, _, _ = timed_region(k3, False)
+        dt3, _, _, _ = timed_region(k3, False)
         recompute_leg = {"switch": "args.activation_recompute=True", "value": round(B * world * k3 / dt3, 3), "unit": "images/s",
                          "ms_per_step": round(dt3 / k3 * 1e3, 3), "steps": k3,
                          "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
@@ -171,33 +327,58 @@ def main():
         for t in model.trunks():
             t.recompute_out = False
 
+    def extra_leg(cfg, warm, steps, with_overlap, recompute_=None):
+        """Another BASELINE.json configuration on this one GPU, riding in the same JSON line (never `value`): W warm-ups, K timed
+        in-order steps with the HIP-event kernel timer -> its own roofline block; optionally the two-stream view overlap."""
+        drop()
+        cc = build(cfg, recompute=recompute_)
+        if rank == 0:
+            print(f"[bench] leg {cc['desc']}: {warm} warm-up + {steps} timed step(s)", file=sys.stderr, flush=True)
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        dtl, tml, ol, _ = timed_region(steps, True)
+        ll = ol["loss"].item()
+        assert ll == ll, f"NaN loss ({cfg} leg)"
+        run["model"].raise_on_nonfinite()
+        leg = {"config": cc["desc"], "command": f"python bench.py --gpus 1 --config {cfg}", "per_gpu_batch": cc["B"],
+               "dtype": cc["enc_dtype"], "value": round(cc["B"] * steps / dtl, 3), "unit": "images/s",
+               "ms_per_step": round(dtl / steps * 1e3, 3), "steps": steps, "warmup": warm,
+               "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "final_loss": ll}
+        if tml is not None:
+            leg["roofline"], leg["kernels"] = roofline_blocks(tml, cc["enc_dtype"], dtl, steps, cfg, cc["desc"])
+        if with_overlap:
+            leg["view_overlap"] = overlap_leg(cc["B"], min(steps, 3))
+        return leg
+
     # Scale anchor (not `value`): the N > 1 runs of this script use C3 (per-GPU batch 64, block outputs recomputed in backward);
     # the N = 1 line is C1 (BASELINE.json's single-GPU config).  So that a 1 -> N efficiency compares EQUAL per-GPU work, the
     # default N = 1 run also times the C3 per-GPU workload on this one GPU (same as `--gpus 1 --config C3`).
-    anchor = None
-    if world == 1 and a.config == "C1" and not a.batch and not a.no_anchor_leg:
-        import gc
-        Ba = CONFIGS["C3"][0]
-        out = None
-        run.clear(); del model, opt, data, y
-        gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
-        args3 = types.SimpleNamespace(mode="train", batch_size=Ba, encoder_depth=depth, activation_recompute=True,
-                                      encoder_dtype=enc_dtype, oct_encoder="slices", oct3d_depth=18)
-        torch.manual_seed(0)
-        m3 = edrl_amd.MedFusion(2, 2, None, args3).to(dev).train()
-        o3 = (torch.optim.Adam if a.torch_adam else edrl_amd.FusedAdam)(m3.parameters(), lr=1e-4, weight_decay=1e-6)
-        d3, y3 = edrl_amd.synthetic_batch(Ba, HW, HW, S, device=dev, seed=1234, rank=rank)
-        run.update(model=m3, opt=o3, data=d3, y=y3)
+    anchor = bf16_leg = c4_leg = None
+    if default_line:
+        out = model = None
+    if default_line and not a.no_anchor_leg:
+        drop()
+        ca = build("C3")
         step(); torch.cuda.synchronize()
         k4 = min(a.steps, 3)
-        dt4, _, o4 = timed_region(k4, False)
+        dt4, _, o4, _ = timed_region(k4, False)
         l4 = o4["loss"].item()
+        del o4
         assert l4 == l4, "NaN loss (scale anchor)"
-        anchor = {"config": CONFIGS["C3"][5], "command": "python bench.py --gpus 1 --config C3", "per_gpu_batch": Ba,
-                  "value": round(Ba * k4 / dt4, 3), "unit": "images/s", "ms_per_step": round(dt4 / k4 * 1e3, 3), "steps": k4,
+        anchor = {"config": ca["desc"], "command": "python bench.py --gpus 1 --config C3", "per_gpu_batch": ca["B"],
+                  "value": round(ca["B"] * k4 / dt4, 3), "unit": "images/s", "ms_per_step": round(dt4 / k4 * 1e3, 3), "steps": k4,
                   "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                   "note": "the per-GPU workload of every N > 1 run of this script, timed on one GPU: divide the N-GPU `value` by "
                           "N x this value for a weak-scaling efficiency on equal per-GPU work"}
+    # The bf16 configurations of BASELINE.json in the driver-timed line (never `value`): C2 (configs[2]) and the per-GPU shape of
+    # C4 (configs[4]: 512x512 fundus + 128-slice OCT, OCT-dropped second view).
+    if default_line and not a.no_bf16_legs:
+        bf16_leg = extra_leg("C2", 2, 5, want_overlap)
+        c4_leg = extra_leg("C4", 1, 3, False)
+        c4_leg["unit"] = "samples/s"
+        c4_leg["note"] = "per-GPU shape of the 8-GPU configuration (B=4 per GPU) on one GPU; the 8-rank run is the driver's"
+    drop()
 
     if rank == 0:
         value = B * world * a.steps / dt
@@ -212,69 +393,9 @@ def main():
             "peak_mem_GiB": round(peak_primary / 2 ** 30, 2),
         }
         if timer is not None:
-            ks = timer.summary()
-            dom = ks.get("conv_gather_bf16" if enc_dtype == "bf16" else "conv_gather")
-            if dom:
-                avg_ms = dom["ms"] / dom["launches"]
-                peak = PEAK_BF16_MFMA_TFLOPS if enc_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-                res["roofline"] = {
-                    "kernel": ("conv_gather_bf16 family (implicit-GEMM conv fwd+dgrad): conv_gather_bf16_v3_kernel (256x256 LDS-DMA core, "
-                               "v_mfma_f32_16x16x32_bf16: K-heavy layers) + conv_gather_bf16_kernel (128-row, v_mfma_f32_32x32x16_bf16: "
-                               "HBM-bound and fused-BatchNorm layers) + conv3x3_c64_bf16_kernel / conv1x1_k64_bf16_kernel (weight-stationary: "
-                               "64-channel 3x3 and expanding 1x1 layers of stages 1-2)"
-                               if enc_dtype == "bf16" else
-                               "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)"),
-                    "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
-                    "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
-                    "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"]),
-                    "algorithmic_flop_per_byte": round(dom["flops"] / dom["bytes"], 2) if dom.get("bytes") else None,
-                    "share_of_step_time": round(dom["ms"] / (dt * 1e3), 4),
-                    # each call priced by whichever of ITS algorithmic flops (MFMA peak) or bytes (8 TB/s) binds: the fused
-                    # BatchNorm layers of stages 1-2 read two K-wide operand tensors and sit on the HBM side of the ridge
-                    "per_call_bound": {"speed_of_light_ms": round(dom["bound_ms"], 3), "measured_ms": round(dom["ms"], 3),
-                                       "frac": round(dom["bound_ms"] / dom["ms"], 4)},
-                    # the same launches split by the resource that binds each call: MFMA-bound calls against the MFMA peak,
-                    # HBM-bound calls (algorithmic bytes / 8 TB/s > flops / peak) in GB/s against the HBM spec
-                    "by_bound": {
-                        "mfma": {"calls": dom["by_bound"]["mfma"]["calls"], "ms": round(dom["by_bound"]["mfma"]["ms"], 3),
-                                 "tflops": round(dom["by_bound"]["mfma"]["tflops"], 3),
-                                 "frac": round(dom["by_bound"]["mfma"]["tflops"] / peak, 4)},
-                        "hbm": {"calls": dom["by_bound"]["hbm"]["calls"], "ms": round(dom["by_bound"]["hbm"]["ms"], 3),
-                                "GBps": round(dom["by_bound"]["hbm"]["GBps"], 1),
-                                "frac_of_8TBps": round(dom["by_bound"]["hbm"]["GBps"] / 8000.0, 4)}} if "by_bound" in dom else None,
-                    "launch_unit": "kernel launches as rocprofv3 counts them (a stride-2 data-gradient call issues one kernel "
-                                   "per non-empty parity class; the HIP events bracket the call); rocprofv3's conv_gather_* rows are these "
-                                   "launches plus the head's Linear layers, which run the same kernels (key linear_gather below)",
-                }
-                if enc_dtype == "bf16":
-                    res["roofline"]["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
-                                               "HBM-bound (50-250 FLOP/B against a ~450 FLOP/B ridge), only the 3x3 layers of "
-                                               "stages 2-4 and the 1x1 layers with >= 1024 input channels are MFMA-bound "
-                                               "(v3 core: 0.95-1.15 PFLOP/s there): profiles/r03_v3_layers_bf16_2112img.txt")
-            res["kernels"] = {}
-            for k, v in ks.items():
-                e = {"launches": v["launches"], "calls": v["calls"], "ms_total": round(v["ms"], 3)}
-                if "GBps" in v and v["flops"] == 0:      # HBM-bound passes: algorithmic bytes / HIP-event time against the 8 TB/s HBM3E spec
-                    e.update(bound="hbm", GBps=round(v["GBps"], 1), frac_of_8TBps=round(v["GBps"] / 8000.0, 4),
-                             algorithmic_bytes=v["bytes"])
-                else:
-                    e.update(bound="mfma", tflops=round(v["tflops"], 3), per_call_bound_frac=round(v["bound_ms"] / v["ms"], 4) if v["ms"] > 0 else None)
-                    if v.get("bytes"):
-                        e.update(algorithmic_GBps=round(v["GBps"], 1), algorithmic_bytes=v["bytes"])
-                res["kernels"][k] = e
-        if "roofline" in res:
-            # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py);
-            # only quoted when those passes ran this very workload.
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_c1.json")))
-                if pm.get("workload") == desc and "conv_gather" in pm.get("kernels", {}):
-                    res["roofline"]["traffic"] = round(pm["kernels"]["conv_gather"]["hbm_bytes_per_launch"])
-                    res["roofline"]["traffic_source"] = ("static: profiles/pmc_traffic_c1.json -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                         "passes of this same command, collected separately (not measured in this run)")
-            except (OSError, ValueError):
-                pass
+            roof, res["kernels"] = roofline_blocks(timer, enc_dtype, dt, a.steps, a.config, desc)
+            if roof:
+                res["roofline"] = roof
         if overlap is not None:
             res["view_overlap"] = overlap
         if recompute_leg is not None:
@@ -283,7 +404,14 @@ def main():
             res["config"]["activation_recompute"] = True
         if anchor is not None:
             res["scale_anchor"] = anchor
+        if bf16_leg is not None:
+            res["bf16_leg"] = bf16_leg
+        if c4_leg is not None:
+            res["c4_leg"] = c4_leg
         if world > 1:
+            res["per_rank_ms_per_step"] = {"min": min(per_rank), "max": max(per_rank), "ranks": per_rank,
+                                           "note": "each rank's own time for the K timed steps (before the closing barrier) / K"}
+            res["grad_exchange"] = exchange
             res["scaling_note"] = ("weak: per-GPU batch fixed at %d for every N > 1 (%s).  The default N = 1 line of this script is C1 "
                                    "(per-GPU batch 32, BASELINE.json's single-GPU config) and carries the matching single-GPU anchor as "
                                    "`scale_anchor` (= `python bench.py --gpus 1 --config %s`): efficiency(N) = value(N) / (N x "

@@ -94,7 +94,7 @@ int edrl_conv2d_nhwc_fwd_bnin_stats_f32(const float* x, const float* in_fcoef, c
                                         int KW, int stride, int pad, hipStream_t stream);
 /* dx [+]= conv_transpose(d_raw(g, yraw; bcoef), w).  With ep_raw != NULL, dx is the gradient of relu?(bn(ep_raw)) of the layer
  * below: the epilogue masks it (ep_mask sign bytes [pixel][Ci/4], or recomputed from ep_raw / ep_fcoef when ep_mask == NULL and
- * ep_relu), stores the masked gradient and writes (sum g, sum g*x) per 128-row tile to
+ * ep_relu), stores the masked gradient and writes (sum g, sum g*(x - mean)), mean = ep_fcoef row 0, per 128-row tile to
  * ep_part [edrl_conv_dgrad_bn_chunks(N,Hi,Wi,stride,pad)][2][Ci].  flags: 2 = accumulate into dx before masking. */
 long edrl_conv_dgrad_bn_chunks(int N, int Hi, int Wi, int stride, int pad);
 int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g, const float* yraw, const float* bcoef, const float* wt, float* dx, int N,
@@ -173,8 +173,8 @@ int edrl_bn_apply_res_f32(const float* x, const float* fcoef, const float* resid
                           unsigned char* relu_mask, long M, int C, int relu, hipStream_t stream);
 /* BatchNorm(+ReLU) backward split for the fused conv kernels.  _reduce: g = dout * relu-mask (optional) -> g_out (optional),
  * partial sums (sum g, sum g*xhat) -> part [ceil(M/1024)][3][C] (edrl_bn_workspace_bytes).  _finalize: partial sums with
- * `planes` planes per chunk (3 from _reduce; 2 from edrl_conv2d_nhwc_dgrad_bn_f32, whose second plane is sum g*x and is
- * converted here in fp64) -> dgamma, dbeta, bcoef [4][C]. */
+ * `planes` planes per chunk (3 from _reduce; 2 from edrl_conv2d_nhwc_dgrad_bn_f32, whose second plane is sum g*(x - mean) and is
+ * scaled by rstd here in fp64) -> dgamma, dbeta, bcoef [4][C]. */
 int edrl_bn_bwd_reduce_f32(const float* dout, const unsigned char* relu_mask, const float* x, const float* fcoef, float* g_out,
                            float* part, size_t part_bytes, long M, int C, hipStream_t stream);
 size_t edrl_bn_bwd_group_ws_bytes(long nchunks, int C);

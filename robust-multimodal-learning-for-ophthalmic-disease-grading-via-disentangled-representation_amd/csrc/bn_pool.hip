@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 // ---- BatchNorm backward finalize from per-tile partial sums part[chunk][planes][C] (plane 0 = sum g, plane 1 = sum g*xhat;
 // the fused data-gradient epilogue emits planes = 2 with one chunk per 128 rows, colstat_kernel<1> planes = 3 per 1024 rows).
-// With planes = 2 plane 1 is sum g*x (raw x; converted to sum g*xhat = rstd*(sum g*x - mean*sum g) here, in fp64).
+// With planes = 2 plane 1 is sum g*(x - mean) (the epilogues subtract the batch mean before the product, so no mean*sum(g) is
+// cancelled afterwards; sum g*xhat = rstd * plane 1, in fp64).
 // -> dgamma, dbeta and bcoef [4][C] = {A = gamma*rstd, nK2 = -A*rstd*mean(g*xhat), C2 = -nK2*mean - A*mean(g), mean}: the
 // coefficients from which the consumers (conv_gemm.hip ATR 2 / DYT 2) form d_raw = A*g + nK2*x + C2 with two packed FMAs.
 __global__ __launch_bounds__(256) void bn_bwd_group_kernel(const float* __restrict__ part, int nchunks, int planes, int C,
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_coef_kernel(const float* 
   double s1 = fin_lane_sum(a1, sh);
   if (q != 0 || c >= C) return;
   const double rs = (double)rstd[c], mu = (double)mean[c];
-  if (planes == 2) s1 = rs * (s1 - mu * s0);      // the conv epilogue accumulates sum g*x: -> sum g*xhat
+  if (planes == 2) s1 = rs * s1;                  // the conv epilogue accumulates sum g*(x - mean): -> sum g*xhat
   if (dbeta) dbeta[c] = (float)s0;
   if (dgamma) dgamma[c] = (float)s1;
   const double A = (double)(gamma ? gamma[c] : 1.f) * rs;

@@ -31,7 +31,7 @@ typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
 //   ATR 1: the gathered operand is a RAW (bf16) conv output; bf16(relu(x*scale + shift2)) is formed while the tile is staged.
 //   ATR 2: the gathered operand is d_raw = bf16(A*g + nK2*x + C2) from the masked gradient g (src) and the raw output x (src2).
 //   EPI 1: the computed tile is the gradient of a BatchNorm(+ReLU) output: masked (sign bytes or decision re-derived from the
-//          raw tensor), stored as bf16, and (sum g, sum g*x) of the UNROUNDED fp32 values go to ep_part.
+//          raw tensor), stored as bf16, and (sum g, sum g*(x - mean)) of the UNROUNDED fp32 values go to ep_part.
 //   MASK : padding taps / masked rows must read as exactly 0 after the transform (false for 1x1 / pad-0 layers).
 // OCC4: compiled for 4 workgroups per CU (128 VGPRs, 4 x 40 KiB of LDS): the forward kernels (plain and with the operand transform,
 // ATR 1): 8 MFMAs per wave and K tile cannot hide a global load, so the K loop runs at about one memory latency per tile and a
@@ -299,10 +299,14 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : 3) void conv_gather_bf16_kernel(con
     float* stage = smem + wave * 32 * SLD;
     const int srow = lane / CV, scv = lane % CV;
     const int n = n0 + wn0 + scv * VW;
-    f32x4 kshift[Q], st0[Q], st1[Q], e_scale[Q], e_shift2[Q];
+    f32x4 kshift[Q], st0[Q], st1[Q], e_scale[Q], e_shift2[Q], e_mean[Q];      // e_mean: plane 1 is sum g*(x - mean), see conv_gemm.hip
 #pragma unroll
-    for (int q = 0; q < Q; ++q) kshift[q] = st0[q] = st1[q] = e_scale[q] = e_shift2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < Q; ++q) kshift[q] = st0[q] = st1[q] = e_scale[q] = e_shift2[q] = e_mean[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI == 1) {
+      if (n < g.NC) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) e_mean[q] = *reinterpret_cast<const f32x4*>(F.ep_fcoef + n + 4 * q);
+      }
       if (n < g.NC && !F.ep_mask) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : 3) void conv_gather_bf16_kernel(con
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xr[e], e_scale[q][e], e_shift2[q][e]) > 0.f ? v[e] : 0.f;
               }
               st0[q] += v;
-              st1[q] = __builtin_elementwise_fma(v, xr, st1[q]);
+              st1[q] = __builtin_elementwise_fma(v, xr - e_mean[q], st1[q]);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) ov[4 * q + e] = (__bf16)v[e];
@@ -924,7 +928,7 @@ int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat
   if (Hi == Ho && Wi == Wo && !((uintptr_t)y & 15) && conv1x1_k64_ok(N, Hi, Wi, Ci, Co, KH, KW, stride, pad))
     return launch_conv1x1_k64(x, nullptr, w, y, N, Hi, Wi, Ci, Co, stat_part, st);                    // 64 -> 128..512 1x1: streaming kernel
   if (Hi == Ho && Wi == Wo && !((uintptr_t)y & 15) && conv3x3_c64_ok(N, Hi, Wi, Ci, Co, KH, KW, stride, pad))
-    return launch_conv3x3_c64(x, w, 0, y, N, Hi, Wi, stat_part, nullptr, nullptr, nullptr, st);   // 64 -> 64 3x3: weight-stationary kernel
+    return launch_conv3x3_c64(x, w, 0, y, N, Hi, Wi, stat_part, nullptr, nullptr, nullptr, nullptr, st);   // 64 -> 64 3x3: weight-stationary kernel
   if (Co <= 64) return launch_gather_bf16<64, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
   return launch_gather_bf16<128, false>((const __bf16*)x, (const __bf16*)w, (__bf16*)y, g, st);
 }
@@ -938,7 +942,7 @@ int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N,
   if (((uintptr_t)dy & 15) || ((uintptr_t)wt & 15) || ((uintptr_t)dx & 7)) return EDRL_EINVAL;
   if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
   if (!(flags & GF_ACCUM) && Hi == Ho && Wi == Wo && !((uintptr_t)dx & 15) && conv3x3_c64_ok(N, Hi, Wi, Co, Ci, KH, KW, stride, pad))
-    return launch_conv3x3_c64(dy, wt, 1, dx, N, Hi, Wi, nullptr, nullptr, nullptr, nullptr, st);
+    return launch_conv3x3_c64(dy, wt, 1, dx, N, Hi, Wi, nullptr, nullptr, nullptr, nullptr, nullptr, st);
   int sshift = 0;
   while ((1 << sshift) < stride) ++sshift;
   if ((1 << sshift) != stride) return EDRL_EINVAL;
@@ -1141,7 +1145,7 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
   if (ep_raw && ep_part_bytes < (size_t)chunks * 2 * Ci * sizeof(float)) return EDRL_ENOSPC;
   if (plain_in && ep_mask && !(flags & GF_ACCUM) && Hi == Ho && Wi == Wo && !((uintptr_t)dx & 15) && !((uintptr_t)ep_raw & 15) &&
       conv3x3_c64_ok(N, Hi, Wi, Co, Ci, KH, KW, stride, pad))
-    return launch_conv3x3_c64(g_in, wt, 1, dx, N, Hi, Wi, nullptr, ep_raw, ep_mask, ep_part, st);
+    return launch_conv3x3_c64(g_in, wt, 1, dx, N, Hi, Wi, nullptr, ep_raw, ep_mask, ep_part, ep_fcoef, st);
   int sshift = 0;
   while ((1 << sshift) < stride) ++sshift;
   if ((1 << sshift) != stride) return EDRL_EINVAL;

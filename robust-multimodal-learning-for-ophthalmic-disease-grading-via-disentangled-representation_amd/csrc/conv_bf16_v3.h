@@ -19,7 +19,7 @@ int launch_wgrad_bf16_v3(const void* dy, const void* x, float* workspace, size_t
 // optional BatchNorm chunk partials; data gradient, flip = 1 on the permuted weights, optionally with the masked-gradient epilogue).
 bool conv3x3_c64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride, int pad);
 int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int N, int H, int W, float* stat_part, const void* ep_x,
-                       const unsigned char* ep_mask, float* ep_part, hipStream_t st);
+                       const unsigned char* ep_mask, float* ep_part, const float* ep_mean, hipStream_t st);
 
 // 1x1 / stride 1 convolution with 64 or 128 input channels and 64 .. 512 output channels on the streaming kernel of conv_c64_bf16.hip
 // (in_fcoef != NULL: BatchNorm + ReLU of the input folded into the operand, fcoef [5][64]); stat_part optional.

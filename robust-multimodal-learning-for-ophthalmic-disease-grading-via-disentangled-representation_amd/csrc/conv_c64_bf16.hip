@@ -25,7 +25,8 @@
 typedef __bf16 c64_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int c64_u32x4 __attribute__((ext_vector_type(4)));
 
-#define C64_LDS (18 * 4 * 64 * 16)     // 72 KiB: [K step][channel tile][lane] x 16 bytes
+#define C64_WBYTES (18 * 4 * 64 * 16)  // 72 KiB: [K step][channel tile][lane] x 16 bytes
+#define C64_LDS (C64_WBYTES + 256)     // + the 64 batch means of the EPI 1 epilogue
 
 struct C64Geom {
   int M, H, W, nchunks;
@@ -35,16 +36,18 @@ struct C64Geom {
 
 // EPI 0: bf16 store (+ BatchNorm chunk partials [chunk][3][64] when stat_part != NULL)
 // EPI 1: the result is the gradient of a BatchNorm+ReLU output: masked with the sign bytes ep_mask [M][16], stored as bf16,
-//        (sum g, sum g*x) with x = ep_x [M][64] (raw conv output of that BatchNorm) -> ep_part [chunk][2][64]
+//        (sum g, sum g*(x - mean)) with x = ep_x [M][64] (raw conv output of that BatchNorm, mean = ep_mean [64]) -> ep_part [chunk][2][64]
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_bf16_kernel(const __bf16* __restrict__ src, const __bf16* __restrict__ w,
                                                                   __bf16* __restrict__ dst, C64Geom g, int flip,
                                                                   float* __restrict__ stat_part, const __bf16* __restrict__ ep_x,
                                                                   const unsigned char* __restrict__ ep_mask,
-                                                                  float* __restrict__ ep_part) {
+                                                                  float* __restrict__ ep_part, const float* __restrict__ ep_mean) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // EPI 1: the batch mean of ep_x's BatchNorm [64] behind the weights (plane 1 of the partials is sum g*(x - mean))
+  if constexpr (EPI == 1) { if (tid < 64) reinterpret_cast<float*>(smem + C64_WBYTES)[tid] = ep_mean[tid]; }
   // ---- weights -> LDS in fragment order: fragment (K step ks = 2*tap + half, channel tile ct), lane l = (row l&15 = channel
   // 16 ct + (l&15), k chunk l>>4 = input channels 32 half + 8 (l>>4) .. +7).  flip (data gradient, w = [Ci][3][3][Co]): tap 8 - t.
   for (int idx = tid; idx < 18 * 4 * 64; idx += 512) {
@@ -235,6 +238,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_bf16_kernel(const __bf16* 
           }
         } else {
           if (ok) {
+            f32x4 em[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              em[q] = *reinterpret_cast<const f32x4*>(smem + C64_WBYTES + 4 * (cb0 + 4 * (q & 1) + 32 * (q >> 1)));
             const c64_bf16x8 x0 = *reinterpret_cast<const c64_bf16x8*>(ep_x + (long)m * 64 + cb0);
             const c64_bf16x8 x1 = *reinterpret_cast<const c64_bf16x8*>(ep_x + (long)m * 64 + cb0 + 32);
             const unsigned mb0 = *reinterpret_cast<const unsigned short*>(ep_mask + (long)m * 16 + (cb0 >> 2));
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_bf16_kernel(const __bf16* 
               for (int e = 0; e < 4; ++e) {
                 const float ve = (mb >> e) & 1 ? v[q][e] : 0.f;
                 v[q][e] = ve;
-                const float xe = (float)(q < 2 ? x0 : x1)[4 * (q & 1) + e];
+                const float xe = (float)(q < 2 ? x0 : x1)[4 * (q & 1) + e] - em[q][e];
                 sa[q][e] += ve;
                 sb[q][e] = __builtin_fmaf(ve, xe, sb[q][e]);
               }
@@ -506,7 +513,7 @@ bool conv3x3_c64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int str
 // src [N,H,W,64] bf16; w: forward [Co][3][3][Ci], data gradient (flip = 1) the permuted [Ci][3][3][Co]; dst [N,H,W,64] bf16.
 // stat_part (forward, optional): [ceil(M/128)][3][64]; ep_x / ep_mask / ep_part (data gradient with epilogue): see the kernel.
 int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int N, int H, int W, float* stat_part, const void* ep_x,
-                       const unsigned char* ep_mask, float* ep_part, hipStream_t st) {
+                       const unsigned char* ep_mask, float* ep_part, const float* ep_mean, hipStream_t st) {
   C64Geom g;
   g.M = (int)((long)N * H * W);
   g.H = H; g.W = W;
@@ -520,12 +527,12 @@ int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int 
   int grid = (g.nchunks + 7) / 8;
   if (grid > 256) grid = 256;
   if (ep_x) {
-    if (!ep_mask || !ep_part) return EDRL_EINVAL;
+    if (!ep_mask || !ep_part || !ep_mean) return EDRL_EINVAL;
     auto kern = conv3x3_c64_bf16_kernel<1>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS); attr = true; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C64_LDS, st, (const __bf16*)src, (const __bf16*)w, (__bf16*)dst, g, flip, stat_part,
-                       (const __bf16*)ep_x, ep_mask, ep_part);
+                       (const __bf16*)ep_x, ep_mask, ep_part, ep_mean);
   } else {
     const char* de = getenv("EDRL_C64_DBG");
     const char* da = getenv("EDRL_ALLOW_DIAGNOSTIC_KERNELS");
@@ -534,7 +541,7 @@ int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int 
       auto kd = dbg == 1 ? conv3x3_c64_bf16_kernel<0, 1> : conv3x3_c64_bf16_kernel<0, 2>;
       (void)hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
       hipLaunchKernelGGL(kd, dim3(grid), dim3(512), C64_LDS, st, (const __bf16*)src, (const __bf16*)w, (__bf16*)dst, g, flip, stat_part,
-                         (const __bf16*)nullptr, (const unsigned char*)nullptr, (float*)nullptr);
+                         (const __bf16*)nullptr, (const unsigned char*)nullptr, (float*)nullptr, (const float*)nullptr);
       EDRL_LAUNCH_CHECK();
       return 0;
     }
@@ -542,7 +549,7 @@ int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS); attr = true; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C64_LDS, st, (const __bf16*)src, (const __bf16*)w, (__bf16*)dst, g, flip, stat_part,
-                       (const __bf16*)nullptr, (const unsigned char*)nullptr, (float*)nullptr);
+                       (const __bf16*)nullptr, (const unsigned char*)nullptr, (float*)nullptr, (const float*)nullptr);
   }
   EDRL_LAUNCH_CHECK();
   return 0;

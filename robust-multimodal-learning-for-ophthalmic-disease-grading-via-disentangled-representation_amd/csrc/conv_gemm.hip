@@ -619,8 +619,11 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const bool stats = EPI == 0 && (g.flags & GF_STATS) != 0;
     f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
     // EPI 1: BatchNorm(+ReLU) backward of the tensor this tile is the gradient of (channels n .. n+3 of this lane)
-    f32x4 e_scale = zero4, e_shift2 = zero4;
+    // e_mean: the partial sum of plane 1 is taken SHIFTED, sum g*(x - mean) (the batch mean is known here, unlike in the forward
+    // statistics), so that the fp64 finalize has no mean*sum(g) to cancel: |mean|/sigma no longer amplifies the fp32 rounding
+    f32x4 e_scale = zero4, e_shift2 = zero4, e_mean = zero4;
     if constexpr (EPI != 0) {
+      if (n < g.NC) e_mean = *reinterpret_cast<const f32x4*>(F.ep_fcoef + n);
       if (n < g.NC && !F.ep_mask) {
         e_scale = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + n);
         e_shift2 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + n);
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
               }
               if constexpr (EPI != 0) {
                 st0 += v;
-                st1 = __builtin_elementwise_fma(v, xr[t], st1);
+                st1 = __builtin_elementwise_fma(v, xr[t] - e_mean, st1);
               }
               if constexpr (OUT16) edrl_buffer_store_b64_soff(edrl_pack_bf16x4(v), ws_d, od(t), so(t, RPP2 * ldd4));
               else edrl_buffer_store_b128_soff(v, ws_d, od(t), so(t, RPP2 * ldd4));
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
               for (int e = 0; e < 4; ++e) v[e] = pre[e] > 0.f ? v[e] : 0.f;
             }
             st0 += v;                                    // sum g
-            st1 = __builtin_elementwise_fma(v, xr, st1); // sum g*x  (-> sum g*xhat in the fp64 finalize)
+            st1 = __builtin_elementwise_fma(v, xr - e_mean, st1); // sum g*(x - mean)  (x rstd = sum g*xhat in the fp64 finalize)
           }
           *reinterpret_cast<f32x4*>(p) = v;
         }
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // staging reads done before the next pass overwrites them
     }
     if constexpr (EPI != 0) {
-      // (sum g, sum g*x) of the tile's valid rows -> F.ep_part[chunk0 + tile_m][2][NC]
+      // (sum g, sum g*(x - mean)) of the tile's valid rows -> F.ep_part[chunk0 + tile_m][2][NC]
 #pragma unroll
       for (int o = 32; o >= C4; o >>= 1) {
 #pragma unroll

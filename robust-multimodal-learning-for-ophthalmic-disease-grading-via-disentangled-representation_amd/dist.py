@@ -21,6 +21,7 @@ the zeros `zero_grad()` left in it.
 import contextlib
 import datetime
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -46,6 +47,9 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force_collective = bool(force_collective) and dist.is_initialized()
         self.collectives_issued = 0      # all-reduces handed to the backend since construction (diagnostics / tests)
+        # step diagnostics (enable_diagnostics): host timestamps + HIP events of backward start / end, of every bucket launch and
+        # around finish()'s wait on the communication stream -- what a first multi-GPU run needs to be read from its JSON
+        self._diag = None
         if params is None:
             params = model.live_parameters() if hasattr(model, "live_parameters") else model.parameters()
         self.params = [p for p in params if p.requires_grad][::-1]
@@ -124,8 +128,48 @@ class GradSync:
         if b["ready"] >= len(b["params"]):
             self._launch(b)
 
-    def _launch(self, b):
+    # ---- diagnostics ------------------------------------------------------------------------------------------------------
+    def enable_diagnostics(self, on=True):
+        """Record, per step: when backward started / ended and when each bucket's all-reduce was ISSUED (host clock and an
+        event on the compute stream), and how long finish() had the compute stream wait for the communication stream
+        (`comm_exposed_ms`: the part of the exchange that backward did not hide).  Read with step_report() after a
+        synchronize.  Costs a handful of events per step; off by default."""
+        self._diag = {"launch": [], "bwd": [None, None], "wait": None} if on else None
+
+    def mark_backward(self, start):
+        """train_step calls this right before / after `loss.backward()` (no-op unless diagnostics are enabled)."""
+        d = self._diag
+        if d is None:
+            return
+        if start:
+            d["launch"], d["wait"] = [], None
+        ev = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)) if self.comm_stream is not None else None
+        d["bwd"][0 if start else 1] = (time.perf_counter(), ev)
+
+    def step_report(self):
+        """Diagnostics of the last finished step (call after torch.cuda.synchronize()): dict, or None when disabled."""
+        d = self._diag
+        if d is None or d["bwd"][0] is None or d["bwd"][1] is None:
+            return None
+        (t0, e0), (t1, e1) = d["bwd"]
+        rep = {"buckets": len(self.buckets), "bytes_exchanged": self.total_bytes(), "collectives_this_step": len(d["launch"]),
+               "backward_host_ms": round((t1 - t0) * 1e3, 3),
+               "launch_host_ms_after_backward_start": [round((t - t0) * 1e3, 3) for t, _, _ in d["launch"]],
+               "launched_in_finish": [bool(f) for _, _, f in d["launch"]]}
+        if d["launch"]:
+            rep["first_launch_host_ms_before_backward_end"] = round((t1 - d["launch"][0][0]) * 1e3, 3)
+        if e0 is not None and e1 is not None:
+            rep["backward_gpu_ms"] = round(e0.elapsed_time(e1), 3)
+            rep["launch_gpu_ms_after_backward_start"] = [round(e0.elapsed_time(ev), 3) for _, ev, _ in d["launch"] if ev is not None]
+            if d["wait"] is not None:
+                rep["comm_exposed_ms"] = round(d["wait"][0].elapsed_time(d["wait"][1]), 3)
+        return rep
+
+    def _launch(self, b, in_finish=False):
         b["launched"] = True
+        if self._diag is not None and (self.world > 1 or self.force_collective):
+            ev = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)) if self.comm_stream is not None else None
+            self._diag["launch"].append((time.perf_counter(), ev, in_finish))
         if self.world == 1 and not self.force_collective:
             return
         inv = 1.0 / self.world
@@ -146,9 +190,13 @@ class GradSync:
         """Call after backward and before optimizer.step(): every gradient is the average over the ranks afterwards."""
         for b in self.buckets:
             if not b["launched"]:                            # a parameter of this bucket saw no gradient in this step
-                self._launch(b)
+                self._launch(b, in_finish=True)
         if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream()
+            w0 = cur.record_event(torch.cuda.Event(enable_timing=True)) if self._diag is not None else None
+            cur.wait_stream(self.comm_stream)
+            if w0 is not None:
+                self._diag["wait"] = (w0, cur.record_event(torch.cuda.Event(enable_timing=True)))
         for b in self.buckets:                               # re-arm: the next backward starts a new exchange even if the
             b["ready"], b["launched"] = 0, False             # caller zeroes gradients some other way than zero_grad()
             b["seen"] = [False] * len(b["params"])

@@ -149,7 +149,12 @@ def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None
     loss_MDD = MK_MMD(combined_features1, combined_features2)
     total = ops.scalar_mix([1.0, 1.0], [loss, loss_MDD])
     predicted = ops.argmax_rows(pred)
+    mark = getattr(grad_sync, "mark_backward", None)      # GradSync diagnostics (no-op unless enabled)
+    if mark is not None:
+        mark(True)
     total.backward()
+    if mark is not None:
+        mark(False)
     if grad_sync is not None:
         (grad_sync.finish if hasattr(grad_sync, "finish") else grad_sync)()
     optimizer.step()

@@ -26,8 +26,9 @@ def collect(d, counter):
     return acc
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+# scripts/gpu_pmc_cfg.sh profiles `bench.py --steps 1 --warmup 1`: two steps per pass (bench.py divides by this for per-step totals)
 out = {"workload": sys.argv[4], "note": "bytes per launch; FETCH_SIZE KiB x1024 x2 (gfx950 half-count correction), WRITE_SIZE KiB x1024",
-       "kernels": {}}
+       "profiled_steps": 2, "kernels": {}}
 for fam in sorted(set(fetch) | set(write)):
     nf, vf = fetch.get(fam, [0, 0.0]); nw, vw = write.get(fam, [0, 0.0])
     n = max(nf, nw)

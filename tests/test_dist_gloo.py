@@ -62,13 +62,21 @@ def _worker(rank, world, port, q):
             with sync.no_sync():
                 (_loss(net, x1[:h], x2[:h]) * 0.5).backward()
             (_loss(net, x1[h:], x2[h:]) * 0.5).backward()
+        elif step == 0:              # exchange diagnostics (bench.py's N > 1 JSON fields), host-clock part: no HIP events on the CPU
+            sync.enable_diagnostics(True)
+            sync.mark_backward(True)
+            _loss(net, x1, x2).backward()
+            sync.mark_backward(False)
         else:
             _loss(net, x1, x2).backward()
         sync.finish()
+        if step == 0:
+            rep = sync.step_report()
+            sync.enable_diagnostics(False)
         res.append({n: p.grad.numpy().copy() for n, p in net.named_parameters() if p.grad is not None})
         assert all(p.grad.data_ptr() == views[n] for n, p in net.named_parameters() if p.grad is not None), \
             "gradients must live in the flat buckets (no gather/scatter copies)"
-    q.put((rank, res, len(sync.buckets), sync.total_bytes()))
+    q.put((rank, res, len(sync.buckets), sync.total_bytes(), rep))
     dist.destroy_process_group()
 
 
@@ -89,8 +97,11 @@ def test_gradsync_world2_matches_single_process():
     g = torch.Generator().manual_seed(5)
     X1, X2 = torch.randn(4, 8, 16, generator=g), torch.randn(4, 8, 16, generator=g)
     live_bytes = sum(p.numel() * 4 for n, p in net.named_parameters() if not n.startswith("dead"))
-    for rank, res, nb, nbytes in outs:
+    for rank, res, nb, nbytes, rep in outs:
         assert nb > 1, "expected several buckets"
+        # every bucket exchanged once, the first one issued by a hook while backward was still running, bytes = live parameters
+        assert rep["collectives_this_step"] == nb and rep["buckets"] == nb and rep["bytes_exchanged"] == live_bytes, rep
+        assert rep["first_launch_host_ms_before_backward_end"] > 0 and not rep["launched_in_finish"][0], rep
         assert nbytes == live_bytes, "dead parameters must not be exchanged"
         for step in range(4):
             net.zero_grad()

@@ -178,7 +178,8 @@ def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, monkey
         gb = gref.reshape(-1, C)[c * 128:min(M, (c + 1) * 128)]
         xb = xraw.double().reshape(-1, C)[c * 128:min(M, (c + 1) * 128)]
         assert float((ev[c, 0].double() - gb.sum(0)).abs().max()) <= 1e-3 * max(float(gb.abs().sum(0).max()), 1e-6), f"chunk {c} sum g"
-        assert float((ev[c, 1].double() - (gb * xb).sum(0)).abs().max()) <= 1e-3 * max(float((gb * xb).abs().sum(0).max()), 1e-6), f"chunk {c} sum g*x"
+        xs = xb - fc[0].double()          # plane 1 is taken shifted by the batch mean (fcoef row 0)
+        assert float((ev[c, 1].double() - (gb * xs).sum(0)).abs().max()) <= 1e-3 * max(float((gb * xs).abs().sum(0).max()), 1e-6), f"chunk {c} sum g*(x-mean)"
 
 
 @pytest.mark.parametrize("M_hw,C,Co", [((2, 14, 14), 64, 256), ((3, 9, 7), 64, 128), ((1, 5, 5), 64, 64), ((5, 16, 13), 64, 512),
@@ -662,9 +663,44 @@ def test_bf16_fused_bn_conv_kernels_vs_fp64(edrl, dev, N, H, W, Ci, Co, k, s, p)
     err = ((nchw(dx.float().cpu()) - ref_dx) * care).abs().max() / ref_dx.abs().max()
     print(f"[parity] bf16 fused dgrad+epilogue: max-rel-err {err:.3e} (tol {2 ** -7:.1e})")
     assert err <= 2 ** -7
-    s_g = (ref_dx * care).sum(dim=(0, 2, 3)); s_gx = (ref_dx * care * nchw(x)).sum(dim=(0, 2, 3))
+    xs = nchw(x) - fin[0].double().view(1, -1, 1, 1)          # plane 1 of the partials: sum g*(x - mean)
+    s_g = (ref_dx * care).sum(dim=(0, 2, 3)); s_gx = (ref_dx * care * xs).sum(dim=(0, 2, 3))
     got = part2.double().sum(0).cpu()
     scale_g = ref_dx.abs().sum(dim=(0, 2, 3)).max()
-    assert ((got[0] - s_g).abs().max() / scale_g) < 2e-3 and ((got[1] - s_gx).abs().max() / (ref_dx.abs() * nchw(x).abs()).sum(dim=(0, 2, 3)).max()) < 2e-3
+    assert ((got[0] - s_g).abs().max() / scale_g) < 2e-3 and ((got[1] - s_gx).abs().max() / (ref_dx.abs() * xs.abs()).sum(dim=(0, 2, 3)).max()) < 2e-3
     dw = ops.conv2d_wgrad_bn_bf16(gyd, yrawd, bcd, xd, find, (Co, k, k, Ci), s, p)
     check("bf16 fused wgrad", dw.cpu().permute(0, 3, 1, 2), w64.grad, 2e-3)
+
+
+@pytest.mark.parametrize("geom,c64", [((4, 14, 14, 64, 64, 3, 1, 1), "0"), ((4, 14, 14, 64, 64, 3, 1, 1), "2"),
+                                      ((4, 14, 14, 128, 64, 1, 1, 0), "0"), ((3, 15, 13, 64, 128, 3, 2, 1), "0"),
+                                      ((6, 12, 12, 256, 64, 1, 1, 0), "0")])
+def test_fused_bn_backward_large_mean_bf16(edrl, dev, geom, c64, monkeypatch):
+    """bf16 counterpart of test_gpu_kernels.py::test_fused_bn_backward_large_mean (|mean| / sigma = 50 in the BatchNorm input): the
+    epilogues of conv_bf16.hip (decision recomputed) and conv_c64_bf16.hip (sign bytes; c64 = "2" forces that kernel) emit
+    (sum g, sum g*(x - mean)) from the UNROUNDED fp32 gradient; dgamma / dbeta vs fp64 autograd on the same bf16-rounded operands at
+    a fixed 1e-4 (the gradient itself is an fp32 accumulation of bf16 products: 2e-5 class), d_raw (edrl_bn_draw_bf16, bf16
+    storage of g and of the result) at two bf16 roundings."""
+    from util import large_mean_case
+    from edrl_amd import encoders as E
+    ops, L = edrl.ops, edrl._lib
+    P = L.ptr
+    monkeypatch.setenv("EDRL_BF16_C64", c64)
+    N, H, W, Ci, Co, k, s, p = geom
+    x, w, dy, gamma, fc, (dg_ref, db_ref, dx_ref), pre, care = large_mean_case(*geom, seed=12, bf16=True)
+    xdv, fcd, dyd = x.bfloat16().to(dev), fc.to(dev), dy.bfloat16().to(dev)
+    wt = ops.permute_weight_bf16(w.to(dev))
+    mask = None
+    if c64 == "2":          # the weight-stationary kernel's epilogue takes the stored sign bytes
+        keep = (pre > 0).permute(0, 2, 3, 1).reshape(N * H * W, Ci // 4, 4).to(torch.uint8)
+        mask = (keep * torch.tensor([1, 2, 4, 8], dtype=torch.uint8)).sum(-1).to(torch.uint8).to(dev)
+    gm, part, chunks = ops.conv2d_dgrad_bn_bf16(dyd, None, None, wt, (N, H, W, Ci), s, p, ep=(xdv, mask, fcd, True))
+    bc, dgam, dbet = E._bcoef_from_partials(part, chunks, 2, N * H * W, gamma.to(dev), fcd)
+    d_raw = torch.empty_like(gm)
+    L.call("edrl_bn_draw_bf16", P(gm), P(xdv), P(bc), P(d_raw), N * H * W, Ci)
+    torch.cuda.synchronize()
+    check(f"bf16 large-mean dbeta {geom}", dbet.cpu(), db_ref, 1e-4)
+    check(f"bf16 large-mean dgamma {geom}", dgam.cpu(), dg_ref, 1e-4)
+    err = ((nchw(d_raw.double().cpu()) - dx_ref) * care).abs().max() / dx_ref.abs().max()
+    print(f"[parity] bf16 large-mean d_raw {geom}: max-rel-err {err:.3e} (tol {2 ** -7:.1e})")
+    assert err <= 2 ** -7

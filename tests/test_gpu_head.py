@@ -269,7 +269,7 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high, depth, B, HW, S, fi
     check("step.loss_MDD", out["loss_MDD"].cpu().view(1), ref["loss_MDD"].view(1), 10 * tol)
     assert torch.equal(out["predicted"].cpu(), ref["predicted"])
     named = dict(m.named_parameters())
-    worst, nchk, worst_fro = 0.0, 0, 0.0
+    worst, nchk, worst_fro, fro_rows = 0.0, 0, 0.0, []
     for n, r in ref["grads"].items():
         key = n
         if ".trunk." in n:      # the trunk registers its tensors with '.' -> '__'
@@ -295,10 +295,13 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high, depth, B, HW, S, fi
             fro = ((g - r).norm() / r.norm().clamp_min(1e-30)).item()
             fro32 = ((r32["grads"][n].double() - r).norm() / r.norm().clamp_min(1e-30)).item()
             worst_fro = max(worst_fro, fro)
+            fro_rows.append((fro, fro32, n))
             assert fro < max(5e-3, 3 * fro32), f"grad {n}: relative Frobenius error {fro:.3e} (fp32 oracle {fro32:.3e})"
             assert e < max(2e-2, 3 * e32), f"grad {n}: worst element {e:.3e} (fp32 oracle {e32:.3e})"
             continue
         assert e < max(5e-3, min(10 * e32, 2e-2)), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
+    for fro, fro32, n in sorted(fro_rows, reverse=True)[:6]:       # per-tensor attribution of the worst cases
+        print(f"[parity]   {n}: relative Frobenius {fro:.3e} (fp32-CPU oracle {fro32:.3e})")
     print(f"[parity] full step: {nchk} gradient tensors, worst rel err vs fp64 oracle {worst:.3e}"
           + (f", worst relative Frobenius {worst_fro:.3e}" if fixed else ""))
     # Adam moved every parameter that has a gradient
