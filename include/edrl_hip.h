@@ -398,6 +398,11 @@ int edrl_adam_chunk_elems(void);
 int edrl_adam_multi_f32(const void* tensors, int n_tensors, const void* chunks, int n_chunks, double lr, double beta1,
                         double beta2, double eps, double weight_decay, long step, hipStream_t stream);
 
+/* Run-time switches (EDRL_* environment variables, csrc/edrl_config.h) are read ONCE at first use; this re-reads them.  For tests
+ * and A/B scripts, between launches (not while other threads launch).  Returns 1 if the library was built with -DEDRL_DIAG
+ * (diagnostic kernel variants present: libedrl_hip_diag.so), 0 for the shipped library. */
+int edrl_config_reload(void);
+
 #ifdef __cplusplus
 }
 #endif

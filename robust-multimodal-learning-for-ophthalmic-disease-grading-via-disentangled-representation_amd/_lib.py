@@ -93,3 +93,17 @@ def call(name, *args):
 def query(name, *args):
     """Invoke a `size_t edrl_*_bytes` helper."""
     return lib().fn[name](*args)
+
+
+def set_switches(**kw):
+    """Change library switches of this process (csrc/edrl_config.h): EDRL_<NAME>=value in the environment, then
+    edrl_config_reload() -- the library reads its environment once, not per launch.  value None removes the variable.
+    Call between launches only.  -> 1 if the loaded library holds the diagnostic kernels (a -DEDRL_DIAG build)."""
+    for k, v in kw.items():
+        if not k.startswith("EDRL_"):
+            raise ValueError(f"not a library switch: {k}")
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    return lib().fn["edrl_config_reload"]()

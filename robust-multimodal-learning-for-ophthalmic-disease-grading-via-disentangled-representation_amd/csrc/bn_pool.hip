@@ -9,6 +9,7 @@
 // Reductions are two-level and ordered (per-chunk fp32 partials, fp64 combine): deterministic,
 // no atomics.
 #include "edrl_common.h"
+#include "edrl_config.h"
 
 #define BN_ROWS_PER_CHUNK 1024
 
@@ -1687,8 +1688,7 @@ int edrl_maxpool3x3s2_bn_fwd_mx(const void* x, int x_bf16, const float* fcoef, v
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !fcoef || (x_bf16 && !y_bf16)) return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(ew_grid((long)N * Ho * Wo * (C / 4)));
-  const char* v8e = getenv("EDRL_STEM_POOL_V8");      // (read per call: tests A/B the two forms in one process)
-  const bool v8_env = !(v8e && v8e[0] == '0');
+  const bool v8_env = edrl_cfg().stem_pool_v8 != 0;     // (A/B switch EDRL_STEM_POOL_V8)
   if (x_bf16 && v8_env && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (((uintptr_t)idx) & 7) == 0)
     hipLaunchKernelGGL(maxpool_bn_fwd8_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 8))), dim3(256), 0, st, (const __bf16*)x, fcoef,
                        (__bf16*)y, idx, N, H, W, C, Ho, Wo);
@@ -1719,8 +1719,7 @@ int edrl_maxpool3x3s2_bn_bwd_reduce_mx(const void* dy, int dy_bf16, const unsign
   if (part_bytes < edrl_bn_workspace_bytes(M, C)) return EDRL_ENOSPC;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256));
-  const char* v8e = getenv("EDRL_STEM_POOL_V8");      // (read per call: tests A/B the two forms in one process)
-  const bool v8_env = !(v8e && v8e[0] == '0');
+  const bool v8_env = edrl_cfg().stem_pool_v8 != 0;     // (A/B switch EDRL_STEM_POOL_V8)
   if (x_bf16 && v8_env && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && (((uintptr_t)idx) & 7) == 0)
     hipLaunchKernelGGL((maxpool_bn_bwd8_kernel<0>), dim3(edrl_cdiv(M, BN_ROWS_PER_CHUNK), edrl_cdiv(C, 256)), dim3(256), 0, st,
                        (const __bf16*)dy, idx, (const __bf16*)x, fcoef, (const float*)nullptr, part, (__bf16*)nullptr, N, H, W, C, Ho, Wo);
@@ -1747,8 +1746,7 @@ int edrl_maxpool3x3s2_bn_bwd_apply_mx(const void* dy, int dy_bf16, const unsigne
     return EDRL_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const dim3 grid(edrl_cdiv((long)N * H * W, MPB_ROWS_PER_BLOCK), edrl_cdiv(C, 256));
-  const char* v8e = getenv("EDRL_STEM_POOL_V8");      // (read per call: tests A/B the two forms in one process)
-  const bool v8_env = !(v8e && v8e[0] == '0');
+  const bool v8_env = edrl_cfg().stem_pool_v8 != 0;     // (A/B switch EDRL_STEM_POOL_V8)
   if (d_bf16 && v8_env && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)d_raw) & 15) == 0 && (((uintptr_t)idx) & 7) == 0)
     hipLaunchKernelGGL((maxpool_bn_bwd8_kernel<1>), grid, dim3(256), 0, st, (const __bf16*)dy, idx, (const __bf16*)x, fcoef, bcoef,
                        (float*)nullptr, (__bf16*)d_raw, N, H, W, C, Ho, Wo);

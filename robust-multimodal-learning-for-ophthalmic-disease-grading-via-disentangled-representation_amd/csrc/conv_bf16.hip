@@ -9,6 +9,7 @@
 // (a K tile never straddles a tap), which holds for every conv of the ResNet trunks except the stem; the stem and
 // the weight gradient stay on the fp32 kernels (conv_gemm.hip) in round 1.
 #include "edrl_common.h"
+#include "edrl_config.h"
 #include <stdlib.h>
 #include <string.h>
 #include "conv_geom.h"
@@ -487,12 +488,12 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   GatherFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   GatherGeom gm = g;
-  { const char* e = getenv("EDRL_BF16_EPI_VW4"); if (e && e[0] == '1') gm.flags |= GF_EPI_VW4; }
-  { const char* e = getenv("EDRL_BF16_KTAIL"); if (e && e[0] == '1') gm.flags |= GF_KTAIL; }     // (A/B) keep the past-the-end load round
+  const EdrlConfig& cfg = edrl_cfg();
+  if (cfg.bf16_epi_vw4 == 1) gm.flags |= GF_EPI_VW4;
+  if (cfg.bf16_ktail == 1) gm.flags |= GF_KTAIL;          // (A/B) keep the past-the-end load round
   if constexpr ((ATR == 1 || (ATR == 0 && BUF)) && EPI == 0 && !DGRAD) {
-    const char* e = getenv("EDRL_BF16_FWD_OCC4");            // (A/B switches, read per call)
-    const char* e0 = getenv("EDRL_BF16_PLAIN_OCC4");         // plain operands: l3 256->1024 0.53 -> 0.48 ms, l4 512->2048 0.39 -> 0.35 ms
-    if (!(e && e[0] == '0') && (ATR == 1 || !(e0 && e0[0] == '0'))) {
+    // (A/B switches EDRL_BF16_FWD_OCC4 / EDRL_BF16_PLAIN_OCC4) plain operands: l3 256->1024 0.53 -> 0.48 ms, l4 512->2048 0.39 -> 0.35 ms
+    if (cfg.bf16_fwd_occ4 != 0 && (ATR == 1 || cfg.bf16_plain_occ4 != 0)) {
       auto k4 = conv_gather_bf16_kernel<BN, DGRAD, BUF, ATR, EPI, MASK, true>;
       static bool attr4 = false;
       if (!attr4) { (void)hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr4 = true; }
@@ -514,9 +515,8 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
 
 template <int BN, bool DGRAD>
 static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st) {
-  static const bool buf_env = []() { const char* e = getenv("EDRL_GATHER_BUF"); return !(e && e[0] == '0'); }();
   const long ohw = (long)g.OHs * g.OWs;
-  const bool buf = buf_env && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 2 < (1L << 31) &&
+  const bool buf = edrl_cfg().gather_buf != 0 && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 2 < (1L << 31) &&
                    (long)g.NC * g.Kfull * 2 < (1L << 31);   // (rows < 2^31: checked by the extern "C" launchers)
   if (buf) return launch_gather_bf16_impl<BN, DGRAD, true>(src, wm, dst, g, st);
   return launch_gather_bf16_impl<BN, DGRAD, false>(src, wm, dst, g, st);
@@ -851,7 +851,7 @@ static void wgrad_plan_h(long P, int Co, int Ktot, int* splits, int* tiles_per_s
   const long tiles = (long)edrl_cdiv(Co, 128) * edrl_cdiv(Ktot, 128);      // (Co <= 64 runs 64-row tiles: the same count)
   const long ptiles = (P + WBK - 1) / WBK;
   // 768 workgroups are resident (256 CUs x 3): aim just under a whole number of rounds (see conv_gemm.hip wgrad_plan)
-  static const long target = []() { const char* e = getenv("EDRL_WGRAD_TARGET_BF16"); return e ? atol(e) : 1536L; }();
+  const long target = edrl_cfg().wgrad_target_bf16;
   long want = target / tiles;
   if (want < 1) want = 1;
   long max_by_len = ptiles / 16; if (max_by_len < 1) max_by_len = 1;
@@ -1026,7 +1026,7 @@ static int wgrad_bf16_impl(const void* dy, const void* x, float* dw, float* work
   constexpr int BM = 128, BN = 128;
   const size_t lds = (size_t)2 * WBK * ((BM + 32) + (BN + 32)) * sizeof(__bf16);
   // Co <= 64 (the 3x3 layers of the first residual stage): 64-row tiles -- half of a 128-row tile's MFMAs would multiply zeros
-  static const bool bm64_env = []() { const char* e = getenv("EDRL_BF16_WGRAD_BM64"); return !(e && e[0] == '0'); }();
+  const bool bm64_env = edrl_cfg().bf16_wgrad_bm64 != 0;
   if (!fuse && Co <= 64 && bm64_env && wgrad_fast_ok_h(Hi, Wi, Ci, Ho, Wo, Co, g.tiles_per_split)) {
     const size_t lds64 = (size_t)2 * WBK * ((64 + 32) + (BN + 32)) * sizeof(__bf16);
     g.tiles_x = edrl_cdiv(g.Ktot, BN); g.tiles_y = 1;
@@ -1041,7 +1041,7 @@ static int wgrad_bf16_impl(const void* dy, const void* x, float* dw, float* work
     EDRL_LAUNCH_CHECK();
     return 0;
   }
-  static const bool fast_env = []() { const char* e = getenv("EDRL_WGRAD_FAST"); return !(e && e[0] == '0'); }();
+  const bool fast_env = edrl_cfg().wgrad_fast != 0;
   const bool fast_ok = wgrad_fast_ok_h(Hi, Wi, Ci, Ho, Wo, Co, g.tiles_per_split);
   const bool fast = fast_env && fast_ok;
   g.tiles_x = edrl_cdiv(g.Ktot, BN); g.tiles_y = edrl_cdiv(Co, BM);

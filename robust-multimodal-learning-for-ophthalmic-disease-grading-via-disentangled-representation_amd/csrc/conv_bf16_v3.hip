@@ -24,6 +24,7 @@
 // One barrier per 32 MFMAs per wave; every DMA has three units (about 3 x 1024 matrix-pipe cycles per SIMD) to land.  Units past
 // the end of K are issued as out-of-range pieces so that the vmcnt arithmetic stays uniform.
 #include "edrl_common.h"
+#include "edrl_config.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -386,8 +387,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
 }
 
 bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad) {
-  const char* env = getenv("EDRL_BF16_V3");            // 0 off, 1 auto (default), 2 force wherever the geometry allows; read per
-  const int mode = env ? atoi(env) : 1;                // call so that one process can A/B the two cores (scripts/v3_layer_bench.py)
+  const int mode = edrl_cfg().bf16_v3;                 // EDRL_BF16_V3: 0 off, 1 auto (default), 2 force wherever the geometry allows
   if (mode == 0) return false;
   const long ohw = (long)g.OHs * g.OWs;
   const bool can = (g.SC % V3_BK == 0) && (g.NC % V3_BN == 0) && (g.ld_dst % 8 == 0) && (g.ld_src % 8 == 0) && ohw > 0 && g.M > 0 &&
@@ -399,7 +399,7 @@ bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad) {
   // wins from K = 512 up (3x3 convs, 1x1 convs with >= 512 input channels: +2..6 % at K = 512; K = 256 loses: one workgroup per
   // CU cannot hide its prologue / epilogue behind so few K units); the data gradient wins at every K that occurs (>= 128), its
   // 128-row counterpart pays more for the scattered / accumulating epilogue.  Both need enough rows to fill the chip once.
-  static const int kmin_f = []() { const char* e = getenv("EDRL_V3_FWD_KMIN"); return e ? atoi(e) : 512; }();
+  const int kmin_f = edrl_cfg().v3_fwd_kmin;
   return g.M >= 256 * 64 && g.Ktot >= (dgrad ? 128 : kmin_f);
 }
 
@@ -411,8 +411,7 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
   if (((uintptr_t)src & 15) || ((uintptr_t)wm & 15) || ((uintptr_t)dst & 15)) return EDRL_EINVAL;
   static bool attr_set[2] = {false, false};
   // EDRL_V3_STAGGER=1: the staggered variant (A/B switch; measured 0-4 % slower than the plain order, see the kernel comment)
-  const char* se = getenv("EDRL_V3_STAGGER");
-  if (se && atoi(se) == 1) {
+  if (edrl_cfg().v3_stagger == 1) {
     auto ks = dgrad ? conv_gather_bf16_v3_kernel<true, 0, true> : conv_gather_bf16_v3_kernel<false, 0, true>;
     (void)hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
     hipLaunchKernelGGL(ks, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);
@@ -424,11 +423,10 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
     if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[1] = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);
   } else {
-    // Diagnostic builds (wrong or absent outputs by construction) need an explicit second switch so that a stray EDRL_V3_DBG in a
-    // production environment cannot silently corrupt a run.
-    const char* de = getenv("EDRL_V3_DBG");
-    const char* da = getenv("EDRL_ALLOW_DIAGNOSTIC_KERNELS");
-    const int dbg = (de && da && atoi(da) == 1) ? atoi(de) : 0;
+#ifdef EDRL_DIAG
+    // Diagnostic builds (wrong or absent outputs by construction): compiled only into libedrl_hip_diag.so (make diag), never into
+    // the shipped library, so no environment can select them in production.
+    const int dbg = edrl_cfg().diag_v3;
     if (dbg >= 1 && dbg <= 4) {     // diagnostic builds: 1 cache-resident loads, 2 no DMA, 3 / 4 in-kernel stamps
       auto kd = dbg == 1 ? conv_gather_bf16_v3_kernel<false, 1> : (dbg == 2 ? conv_gather_bf16_v3_kernel<false, 2> : (dbg == 3 ? conv_gather_bf16_v3_kernel<false, 3> : conv_gather_bf16_v3_kernel<false, 4>));
       (void)hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
@@ -438,6 +436,7 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
       EDRL_LAUNCH_CHECK();
       return 0;
     }
+#endif
     auto kern = conv_gather_bf16_v3_kernel<false>;
     if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[0] = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);

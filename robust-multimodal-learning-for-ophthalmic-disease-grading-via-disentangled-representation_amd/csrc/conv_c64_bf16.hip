@@ -18,6 +18,7 @@
 // are 32 registers accumulated over the chunk and reduced over the 16 pixel lanes once per 128 pixels, from the unrounded fp32
 // accumulators (same contracts as conv_bf16.hip's epilogues).
 #include "edrl_common.h"
+#include "edrl_config.h"
 #include <stdlib.h>
 #include <string.h>
 #include "conv_bf16_v3.h"
@@ -454,8 +455,7 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, KS == 2 ? 2 : 1) void conv1x1_
 }
 
 bool conv1x1_k64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride, int pad) {
-  const char* env = getenv("EDRL_BF16_K64");           // 0 off, 1 auto (default), 2 wherever the geometry allows (read per call)
-  const int mode = env ? atoi(env) : 1;
+  const int mode = edrl_cfg().bf16_k64;                // EDRL_BF16_K64: 0 off, 1 auto (default), 2 wherever the geometry allows
   if (mode == 0) return false;
   if ((Ci != 64 && Ci != 128) || (Co % 64) || Co < 64 || Co > 512 || KH != 1 || KW != 1 || stride != 1 || pad != 0 || N <= 0) return false;
   const long M = (long)N * H * W;
@@ -501,8 +501,7 @@ static int c64_ceil_log2(unsigned d) {
 }
 
 bool conv3x3_c64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride, int pad) {
-  const char* env = getenv("EDRL_BF16_C64");           // 0 off, 1 auto (default), 2 wherever the geometry allows (read per call)
-  const int mode = env ? atoi(env) : 1;
+  const int mode = edrl_cfg().bf16_c64;                // EDRL_BF16_C64: 0 off, 1 auto (default), 2 wherever the geometry allows
   if (mode == 0) return false;
   if (Ci != 64 || Co != 64 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || N <= 0 || H < 2 || W < 2) return false;
   const long M = (long)N * H * W;
@@ -534,9 +533,8 @@ int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C64_LDS, st, (const __bf16*)src, (const __bf16*)w, (__bf16*)dst, g, flip, stat_part,
                        (const __bf16*)ep_x, ep_mask, ep_part, ep_mean);
   } else {
-    const char* de = getenv("EDRL_C64_DBG");
-    const char* da = getenv("EDRL_ALLOW_DIAGNOSTIC_KERNELS");
-    const int dbg = (de && da && atoi(da) == 1) ? atoi(de) : 0;      // diagnostic builds (wrong outputs): 1 no tap shifts, 2 no loads
+#ifdef EDRL_DIAG
+    const int dbg = edrl_cfg().diag_c64;      // diagnostic builds (wrong outputs; libedrl_hip_diag.so only): 1 no tap shifts, 2 no loads
     if (dbg == 1 || dbg == 2) {
       auto kd = dbg == 1 ? conv3x3_c64_bf16_kernel<0, 1> : conv3x3_c64_bf16_kernel<0, 2>;
       (void)hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
@@ -545,6 +543,7 @@ int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int 
       EDRL_LAUNCH_CHECK();
       return 0;
     }
+#endif
     auto kern = conv3x3_c64_bf16_kernel<0>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS); attr = true; }

@@ -20,6 +20,7 @@
 // Global->LDS is register staged and double buffered (one barrier per K tile):
 // tile t+1's loads are issued before tile t's MFMAs and written after them.
 #include "edrl_common.h"
+#include "edrl_config.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
@@ -955,7 +956,7 @@ static int dispatch_gather_fused(const float* src, const float* wm, float* dst, 
   if (!gather_fused_ok(src, wm, dst, g0)) return EDRL_EINVAL;
   GatherGeom g = g0;
   g.flags |= GF_VEC_EPI;
-  static const int small_grid = []() { const char* e = getenv("EDRL_NARROW_BELOW"); return e ? atoi(e) : 512; }();
+  const int small_grid = edrl_cfg().narrow_below;
   const bool narrow = g.NC <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(g.NC, 128) < small_grid);
   const bool mask = !(g.KH == 1 && g.KW == 1 && g.pad == 0);   // 1x1 / pad 0: no padding taps, no masked rows below M
   if (narrow) {
@@ -1057,7 +1058,7 @@ __global__ __launch_bounds__(256) void linear_smallm_f32_kernel(const float* __r
 // Geometry test + launch; returns -1 when the small-M kernel does not apply
 static int try_linear_smallm(const float* src, const float* wm, float* dst, const float* bias, const float* mul,
                              const GatherGeom& g, hipStream_t st) {
-  static const bool on = []() { const char* e = getenv("EDRL_LINEAR_SMALLM"); return !(e && e[0] == '0'); }();
+  const bool on = edrl_cfg().linear_smallm != 0;
   if (!on || g.KH != 1 || g.KW != 1 || g.pad != 0 || g.step != 1 || g.stride != 1 || g.OHs * g.OWs != 1 || g.SH * g.SW != 1) return -1;
   if (g.M > 64 || g.M <= 0 || (g.NC % 16) || (g.Ktot % 128) || g.Ktot != g.Kfull || (g.ld_src % 4) || (g.flags & ~(GF_RELU | GF_ACCUM)))
     return -1;
@@ -1083,7 +1084,7 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
                    (((uintptr_t)src & 15) == 0) && (((uintptr_t)wm & 15) == 0);
   // 64-wide N tiles for Cout <= 64 and for small grids (the head's Linear layers at 32..1568 rows leave most of the
   // 256 CUs idle with 128-wide tiles: twice the workgroups, same work each K step)
-  static const int small_grid = []() { const char* e = getenv("EDRL_NARROW_BELOW"); return e ? atoi(e) : 512; }();
+  const int small_grid = edrl_cfg().narrow_below;
   const bool narrow = g.NC <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(g.NC, 128) < small_grid);
   GatherGeom gv = g;
   if (vec && (g.NC % 4 == 0) && (g.ld_dst % 4 == 0) && (((uintptr_t)dst & 15) == 0) &&
@@ -1093,7 +1094,7 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
     const GatherGeom& g = gv;
     // K tile 16 -> 40 KiB of LDS and 128 VGPRs per workgroup: 3 workgroups (12 waves) per CU.  Measured on the
     // ResNet-50 layer shapes (1024 images): +13 % over K tile 32 / 2 workgroups per CU (profiles/).
-    static const int variant = getenv("EDRL_GATHER_VARIANT") ? atoi(getenv("EDRL_GATHER_VARIANT")) : 1;
+    const int variant = edrl_cfg().gather_variant;
     if (variant == 0) {   // K tile 32, 2 workgroups per CU (kept for A/B runs)
       if (narrow) return launch_gather_v2<128, 64, DGRAD, 32, 2, false>(src, wm, dst, bias, mul, g, st);
       return launch_gather_v2<128, 128, DGRAD, 32, 2, false>(src, wm, dst, bias, mul, g, st);
@@ -1101,7 +1102,7 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
     const bool fast = (g.SC % 16 == 0) && variant != 3;
     if (fast) {
       // buffer-descriptor path: 128 rows touch at most 128/(OHs*OWs) + 2 images; both footprints must fit 31 bits
-      static const bool buf_env = []() { const char* e = getenv("EDRL_GATHER_BUF"); return !(e && e[0] == '0'); }();
+      const bool buf_env = edrl_cfg().gather_buf != 0;
       const long ohw = (long)g.OHs * g.OWs;
       const bool buf = buf_env && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) &&
                        (long)g.NC * g.Kfull * 4 < (1L << 31);   // (rows < 2^31: checked by the extern "C" launchers)
@@ -1561,7 +1562,7 @@ static void wgrad_plan(long P, int Co, int Ktot, int taps, int* bm, int* bn, int
   // Workgroups per launch (1024 are resident: 256 CUs x 4).  Measured on the ResNet-50 shapes (profiles/): multi-tap
   // convs gain 5-15 % from 3 rounds of shorter pixel ranges (the taps' re-reads of X stay in L2), 1x1 convs are best
   // at 1.5 rounds (fewer partial slabs to reduce).
-  static const long target_env = []() { const char* e = getenv("EDRL_WGRAD_TARGET"); return e ? atol(e) : 0L; }();
+  const long target_env = edrl_cfg().wgrad_target;
   const long target = target_env > 0 ? target_env : (taps > 1 ? 3072L : 1536L);
   long want = target / tiles;                       // floor: just under a whole number of rounds, never just over
   if (want < 1) want = 1;
@@ -1748,7 +1749,7 @@ static int wgrad_impl(const float* dy, const float* x, float* dw, float* workspa
   if (workspace_bytes < need || workspace == nullptr) return EDRL_ENOSPC;
   const bool vec = (Ci % 4 == 0) && (ld_x % 4 == 0) && (Co % 4 == 0) && (ld_dy % 4 == 0) &&
                    (((uintptr_t)dy & 15) == 0) && (((uintptr_t)x & 15) == 0);
-  static const bool fast_env = []() { const char* e = getenv("EDRL_WGRAD_FAST"); return !(e && e[0] == '0'); }();
+  const bool fast_env = edrl_cfg().wgrad_fast != 0;
   const bool fast_ok = wgrad_fast_ok(dy, x, Hi, Wi, Ci, Ho, Wo, Co, ld_dy, ld_x, g.tiles_per_split);
   const bool fast = fast_ok && fast_env;
   int rc;

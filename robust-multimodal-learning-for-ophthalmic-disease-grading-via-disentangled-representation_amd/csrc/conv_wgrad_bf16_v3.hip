@@ -22,6 +22,7 @@
 // Split-K over pixel ranges: (Co/256)*(Ktot/256) tiles x `splits` <= 256 workgroups (one per CU, one round), fp32 partial slabs
 // [split][Co][Ktot] reduced in fixed order by splitk_reduce_h_kernel (deterministic), as the 128x128 kernel of conv_bf16.hip.
 #include "edrl_common.h"
+#include "edrl_config.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -249,8 +250,7 @@ static void wgrad_v3_plan(long P, int Co, int Ktot, int* splits, int* units_per_
 }
 
 bool wgrad_bf16_v3_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad) {
-  const char* env = getenv("EDRL_BF16_WGRAD_V3");      // 0 off, 1 auto (default), 2 force wherever the geometry allows
-  const int mode = env ? atoi(env) : 1;
+  const int mode = edrl_cfg().bf16_wgrad_v3;           // EDRL_BF16_WGRAD_V3: 0 off, 1 auto (default), 2 force wherever the geometry allows
   if (mode == 0) return false;
   if ((Co % 256) || (Ci % 256) || N <= 0 || stride <= 0) return false;
   const long P = (long)N * Ho * Wo, ohw = (long)Ho * Wo;

@@ -18,8 +18,9 @@ __device__ __forceinline__ v3_i32x4 v3_make_srd(const void* base, unsigned bytes
 // One LDS-DMA piece (64 lanes x 16 bytes -> 1 KiB of LDS at `lds`, wave-uniform) issued from inline asm: hipcc does not see it, so
 // it neither counts it in vmcnt nor inserts its own conservative "LDS write pending" waits in front of ds_reads when the loop
 // body has control flow (the builtin form made it drain vmcnt inside the staggered loop); every wait is placed by hand below.
-// M0 carries the LDS destination and is written in the same statement (cdna_hip_programming.md 5.7).
+// M0 carries the LDS destination and is written in the same statement (cdna_hip_programming.md 5.7); it is declared clobbered so
+// that the compiler never keeps a value of its own in M0 across the statement.
 __device__ __forceinline__ void v3_dma16(unsigned lds, unsigned voff, v3_i32x4 srd, int soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(srd), "s"(soff) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
 }
 

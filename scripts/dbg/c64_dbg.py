@@ -10,7 +10,8 @@ x = torch.randn(N, 56, 56, 64, device=dev).bfloat16()
 w = (torch.randn(64, 3, 3, 64, device=dev) * 0.05).bfloat16()
 wt = ops.permute_weight_bf16(w.float())
 dx = torch.empty_like(x)
-os.environ["EDRL_ALLOW_DIAGNOSTIC_KERNELS"] = "1"
+# needs the diagnostic build: `make -C <package>/csrc diag` and EDRL_LIB_PATH=<package>/libedrl_hip_diag.so (the shipped library holds no
+# diagnostic kernels)
 def t(fn, reps=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -19,6 +20,6 @@ def t(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 for dbg in ("0", "1", "2"):
-    os.environ["EDRL_C64_DBG"] = dbg
+    assert edrl_amd._lib.set_switches(EDRL_C64_DBG=dbg) == 1, "load libedrl_hip_diag.so (EDRL_LIB_PATH)"
     print("dbg", dbg, "fwd+stats %.3f ms" % t(lambda: ops.conv2d_fwd_bf16(x, w, 1, 1, stats=True)),
           "fwd %.3f ms" % t(lambda: ops.conv2d_fwd_bf16(x, w, 1, 1)), "dgrad %.3f ms" % t(lambda: ops.conv2d_dgrad_bf16(x, wt, tuple(x.shape), 1, 1, out=dx)), flush=True)

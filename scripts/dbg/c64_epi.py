@@ -21,6 +21,6 @@ def t(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 for mode in ("0", "1"):
-    os.environ["EDRL_BF16_C64"] = mode
+    edrl_amd._lib.set_switches(EDRL_BF16_C64=mode)
     print("C64", mode, "dgrad %.3f ms" % t(lambda: ops.conv2d_dgrad_bf16(x, wt, tuple(x.shape), 1, 1, out=dx)),
           "dgrad+epilogue %.3f ms" % t(lambda: ops.conv2d_dgrad_bn_bf16(x, None, None, wt, tuple(x.shape), 1, 1, out=dx, ep=(xr, mask, fc, True))), flush=True)

@@ -11,7 +11,9 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-os.environ["EDRL_BF16_V3"] = "2"; os.environ["EDRL_ALLOW_DIAGNOSTIC_KERNELS"] = "1"
+# needs the diagnostic build: `make -C <package>/csrc diag` and EDRL_LIB_PATH=<package>/libedrl_hip_diag.so (the shipped library holds no
+# diagnostic kernels)
+os.environ["EDRL_BF16_V3"] = "2"
 for name, Ci, H, Co, k, s, p in [("l3 3x3 256", 256, 14, 256, 3, 1, 1), ("l4 3x3 512", 512, 7, 512, 3, 1, 1), ("l4 1x1 2048-512", 2048, 7, 512, 1, 1, 0), ("l3 1x1 1024-256", 1024, 14, 256, 1, 1, 0)]:
     x = torch.randn(N, H, H, Ci, device=dev).bfloat16()
     wb = (torch.randn(Co, k, k, Ci, device=dev) * 0.05).bfloat16()
@@ -19,7 +21,7 @@ for name, Ci, H, Co, k, s, p in [("l3 3x3 256", 256, 14, 256, 3, 1, 1), ("l4 3x3
     flop = 2.0 * N * Ho * Ho * Co * k * k * Ci
     r = []
     for dbg in ("0", "1", "2"):
-        os.environ["EDRL_V3_DBG"] = dbg
+        assert edrl_amd._lib.set_switches(EDRL_V3_DBG=dbg) == 1, "load libedrl_hip_diag.so (EDRL_LIB_PATH)"
         t = timeit(lambda: ops.conv2d_fwd_bf16(x, wb, s, p))
         r.append(f"dbg{dbg}: {t:.3f} ms {flop/t/1e9:6.0f} TF")
     tiles = ((N * Ho * Ho + 255) // 256) * (Co // 256)

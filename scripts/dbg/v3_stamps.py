@@ -6,7 +6,9 @@ from edrl_amd import _lib as L
 P = L.ptr
 dev = torch.device("cuda:0")
 N = 2112
-os.environ["EDRL_BF16_V3"] = "2"; os.environ["EDRL_V3_DBG"] = "3"; os.environ["EDRL_ALLOW_DIAGNOSTIC_KERNELS"] = "1"
+# needs the diagnostic build: `make -C <package>/csrc diag` and EDRL_LIB_PATH=<package>/libedrl_hip_diag.so (the shipped library holds no
+# diagnostic kernels)
+os.environ["EDRL_BF16_V3"] = "2"; os.environ["EDRL_V3_DBG"] = "3"
 for name, Ci, H, Co, k, s, p in [("l3 3x3 256", 256, 14, 256, 3, 1, 1), ("l4 1x1 2048-512", 2048, 7, 512, 1, 1, 0)]:
     x = torch.randn(N, H, H, Ci, device=dev).bfloat16()
     wb = (torch.randn(Co, k, k, Ci, device=dev) * 0.05).bfloat16()

@@ -33,7 +33,7 @@ MODES = {"old": {"EDRL_BF16_V3": "0", "EDRL_V3_STAGGER": "0"}, "v3": {"EDRL_BF16
 
 
 def setmode(m):
-    os.environ.update(MODES[m])
+    os.environ.update(MODES[m]); edrl_amd._lib.set_switches()      # the library reads its environment once: re-read
 
 
 def ab(fn, rounds=3):

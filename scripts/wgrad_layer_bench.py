@@ -31,7 +31,7 @@ def ab(fn, rounds=3):
     best = {m: 1e9 for m in MODES}
     for r in range(rounds + 1):
         for m in MODES:
-            os.environ["EDRL_BF16_WGRAD_V3"] = MODES[m]
+            edrl_amd._lib.set_switches(EDRL_BF16_WGRAD_V3=MODES[m])
             t = timeit(fn, 1 if r == 0 else 3)
             if r:
                 best[m] = min(best[m], t)
@@ -50,8 +50,8 @@ for name, Ci, H, Co, k, s, p, cnt in L:
     flop = 2.0 * N * Ho * Ho * Co * k * k * Ci
     dw = torch.empty(Co, k, k, Ci, device=dev)
     f = lambda: ops.conv2d_wgrad_bf16(dy, x, (Co, k, k, Ci), s, p, out=dw)
-    os.environ["EDRL_BF16_WGRAD_V3"] = "0"; f(); torch.cuda.synchronize(); d0 = dw.clone()
-    os.environ["EDRL_BF16_WGRAD_V3"] = "2"; f(); torch.cuda.synchronize()
+    edrl_amd._lib.set_switches(EDRL_BF16_WGRAD_V3="0"); f(); torch.cuda.synchronize(); d0 = dw.clone()
+    edrl_amd._lib.set_switches(EDRL_BF16_WGRAD_V3="2"); f(); torch.cuda.synchronize()
     err = float((dw - d0).abs().max() / d0.abs().max())
     t = ab(f)
     print(f"{name:20s} {flop/1e9:7.1f} | " + " ".join(f"{t[m]:6.3f} ({flop / t[m] / 1e9:4.0f})" for m in MODES) + f" | {err:.1e}  x{cnt}", flush=True)

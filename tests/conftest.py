@@ -27,3 +27,20 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def switches():
+    """Set EDRL_* library switches for one test (environment + edrl_config_reload(): the library reads its environment once);
+    the previous values are restored and re-read afterwards.  Usage: switches(EDRL_BF16_V3="2")."""
+    import edrl_amd
+    saved = {}
+
+    def set_(**kw):
+        for k in kw:
+            saved.setdefault(k, os.environ.get(k))
+        edrl_amd._lib.set_switches(**kw)
+
+    yield set_
+    if saved:
+        edrl_amd._lib.set_switches(**saved)

@@ -71,7 +71,7 @@ V3_CASES = [
 
 
 @pytest.mark.parametrize("case", V3_CASES)
-def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
+def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, switches):
     """The 256x256 LDS-DMA core (csrc/conv_bf16_v3.hip), forced on (EDRL_BF16_V3=2) at sizes far below its production range:
     forward (+ fused BatchNorm chunk partials), data gradient (plain, accumulating, stride-2 parity classes) against the fp64
     convolution of the same bf16 operands at one bf16 ulp of the output range, the chunk partials against sums taken from the
@@ -91,7 +91,7 @@ def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
     Ho, Wo = y.shape[2], y.shape[3]
     outs = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("EDRL_BF16_V3", mode)
+        switches(EDRL_BF16_V3=mode)
         yh, part, chunks = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), s, p, stats=True)
         dxh = dxa = None
         if Ci % 256 == 0:
@@ -125,7 +125,7 @@ def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
 
 
 @pytest.mark.parametrize("N,H,W", [(2, 14, 14), (3, 9, 7), (1, 2, 2), (5, 16, 13), (1, 23, 3)])
-def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, monkeypatch):
+def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, switches):
     """The weight-stationary 64 -> 64 3x3 kernel (csrc/conv_c64_bf16.hip; weights in LDS in fragment order, pixel fragments straight
     from global memory, lane-pair swap for 16-byte stores), forced on (EDRL_BF16_C64=2) at sizes far below its production range --
     pixel counts that are not multiples of 16 / 64 / 128, 2x2 images (every tap but the centre row / column masked), several images
@@ -149,7 +149,7 @@ def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, monkey
     fc = torch.ones(5, C)
     outs = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("EDRL_BF16_C64", mode)
+        switches(EDRL_BF16_C64=mode)
         yh, part, chunks = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), 1, 1, stats=True)
         wt = ops.permute_weight_bf16(w.float().to(dev))
         dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
@@ -184,7 +184,7 @@ def test_conv3x3_c64_kernel_vs_fp64_and_128row_kernel(edrl, dev, N, H, W, monkey
 
 @pytest.mark.parametrize("M_hw,C,Co", [((2, 14, 14), 64, 256), ((3, 9, 7), 64, 128), ((1, 5, 5), 64, 64), ((5, 16, 13), 64, 512),
                                        ((2, 14, 14), 128, 512), ((3, 9, 7), 128, 128), ((5, 16, 13), 128, 256)])
-def test_conv1x1_k64_streaming_kernel_vs_fp64_and_128row_kernel(edrl, dev, M_hw, C, Co, monkeypatch):
+def test_conv1x1_k64_streaming_kernel_vs_fp64_and_128row_kernel(edrl, dev, M_hw, C, Co, switches):
     """The streaming 64 | 128 -> Co 1x1 kernel (csrc/conv_c64_bf16.hip: weights in LDS, a wave owns 128 pixels x all output channels, pixel
     fragments loaded and transformed in registers once per chunk), forced on (EDRL_BF16_K64=2) at small sizes (pixel counts off every
     tile size, one case below a single chunk): plain forward with BatchNorm chunk partials and the fused form (BatchNorm + ReLU of the
@@ -199,7 +199,7 @@ def test_conv1x1_k64_streaming_kernel_vs_fp64_and_128row_kernel(edrl, dev, M_hw,
     fc[2] = 0.5 + torch.rand(C, generator=g); fc[4] = 0.3 * torch.randn(C, generator=g)
     outs = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("EDRL_BF16_K64", mode)
+        switches(EDRL_BF16_K64=mode)
         y0, p0, ch = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), 1, 0, stats=True)
         y1, p1, _ = ops.conv2d_fwd_bnin_stats_bf16(x.to(dev), fc.to(dev), w.to(dev), 1, 0)
         torch.cuda.synchronize()
@@ -237,7 +237,7 @@ W3_CASES = [
 
 
 @pytest.mark.parametrize("case", W3_CASES)
-def test_conv_wgrad_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
+def test_conv_wgrad_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, switches):
     """The 256x256 LDS-DMA weight-gradient core (csrc/conv_wgrad_bf16_v3.hip: transposing LDS reads of DMA-written pixel-major
     images, X-row offsets decoded once per workgroup into an LDS table), forced on (EDRL_BF16_WGRAD_V3=2) far below its production
     range, against the fp64 weight gradient of the same bf16 operands (fp32 result: only fp32 accumulation error, 2e-5 of the
@@ -257,7 +257,7 @@ def test_conv_wgrad_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
     xh = x.to(dev)
     outs = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("EDRL_BF16_WGRAD_V3", mode)
+        switches(EDRL_BF16_WGRAD_V3=mode)
         dw = ops.conv2d_wgrad_bf16(dyh, xh, (Co, k, k, Ci), s, p)
         dw_again = ops.conv2d_wgrad_bf16(dyh, xh, (Co, k, k, Ci), s, p)
         dwa = ops.conv2d_wgrad_bf16(dyh, xh, (Co, k, k, Ci), s, p, out=dw.clone(), accumulate=True)
@@ -271,7 +271,7 @@ def test_conv_wgrad_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, monkeypatch):
 
 
 @pytest.mark.parametrize("v8", ["0", "1"])
-def test_fused_stem_mx_matches_fp32_kernels(edrl, dev, v8, monkeypatch):
+def test_fused_stem_mx_matches_fp32_kernels(edrl, dev, v8, switches):
     """The bf16 trunk's stem (BatchNorm + ReLU folded into the 3x3/s2 max-pool, edrl_maxpool3x3s2_bn_*_mx): the pooled tensor is
     the fp32 kernel's result rounded to bf16 ONCE (bit-exact), the arg-max bytes are identical, and the two backward kernels fed
     a bf16 gradient equal the fp32 kernels fed the same values as fp32, bit for bit (same arithmetic behind an exact widening
@@ -280,7 +280,7 @@ def test_fused_stem_mx_matches_fp32_kernels(edrl, dev, v8, monkeypatch):
     P = L.ptr
     # v8 = 1: the all-bf16 calls below run the 8-channels-per-thread kernels (EDRL_STEM_POOL_V8, the default): forward and d_raw
     # stay bit-identical; their partial sums are taken in another order (32 row lanes instead of 16), hence 1e-6 instead of equality
-    monkeypatch.setenv("EDRL_STEM_POOL_V8", v8)
+    switches(EDRL_STEM_POOL_V8=v8)
     N, H, W, C = 3, 37, 29, 64
     g = torch.Generator().manual_seed(8)
     raw = torch.randn(N, H, W, C, generator=g).to(dev)
@@ -675,7 +675,7 @@ def test_bf16_fused_bn_conv_kernels_vs_fp64(edrl, dev, N, H, W, Ci, Co, k, s, p)
 @pytest.mark.parametrize("geom,c64", [((4, 14, 14, 64, 64, 3, 1, 1), "0"), ((4, 14, 14, 64, 64, 3, 1, 1), "2"),
                                       ((4, 14, 14, 128, 64, 1, 1, 0), "0"), ((3, 15, 13, 64, 128, 3, 2, 1), "0"),
                                       ((6, 12, 12, 256, 64, 1, 1, 0), "0")])
-def test_fused_bn_backward_large_mean_bf16(edrl, dev, geom, c64, monkeypatch):
+def test_fused_bn_backward_large_mean_bf16(edrl, dev, geom, c64, switches):
     """bf16 counterpart of test_gpu_kernels.py::test_fused_bn_backward_large_mean (|mean| / sigma = 50 in the BatchNorm input): the
     epilogues of conv_bf16.hip (decision recomputed) and conv_c64_bf16.hip (sign bytes; c64 = "2" forces that kernel) emit
     (sum g, sum g*(x - mean)) from the UNROUNDED fp32 gradient; dgamma / dbeta vs fp64 autograd on the same bf16-rounded operands at
@@ -685,7 +685,7 @@ def test_fused_bn_backward_large_mean_bf16(edrl, dev, geom, c64, monkeypatch):
     from edrl_amd import encoders as E
     ops, L = edrl.ops, edrl._lib
     P = L.ptr
-    monkeypatch.setenv("EDRL_BF16_C64", c64)
+    switches(EDRL_BF16_C64=c64)
     N, H, W, Ci, Co, k, s, p = geom
     x, w, dy, gamma, fc, (dg_ref, db_ref, dx_ref), pre, care = large_mean_case(*geom, seed=12, bf16=True)
     xdv, fcd, dyd = x.bfloat16().to(dev), fc.to(dev), dy.bfloat16().to(dev)

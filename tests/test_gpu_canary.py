@@ -134,7 +134,7 @@ BF16_GEOMS = [  # N, H, W, Ci, Co, k, stride, pad : channel counts the 256x256 L
 
 @pytest.mark.parametrize("mode", ["0", "2"])
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", BF16_GEOMS)
-def test_bf16_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, Co, k, s, p, mode, monkeypatch):
+def test_bf16_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, Co, k, s, p, mode, switches):
     """The same guard-band check for the bf16 launchers: forward (+ BatchNorm partials), data gradient (write / accumulate), weight
     gradient incl. its split-K workspace -- once on the 128-row / 128x128 kernels (mode 0) and once with the 256x256 LDS-DMA cores and
     the weight-stationary kernels forced wherever the geometry allows (mode 2: conv_bf16_v3.hip, conv_wgrad_bf16_v3.hip,
@@ -142,10 +142,10 @@ def test_bf16_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, C
     neither fault nor leak into the outputs)."""
     ops, L = edrl.ops, edrl._lib
     P = L.ptr
-    monkeypatch.setenv("EDRL_BF16_V3", mode)
-    monkeypatch.setenv("EDRL_BF16_WGRAD_V3", mode)
-    monkeypatch.setenv("EDRL_BF16_C64", mode)
-    monkeypatch.setenv("EDRL_BF16_K64", mode)
+    switches(EDRL_BF16_V3=mode)
+    switches(EDRL_BF16_WGRAD_V3=mode)
+    switches(EDRL_BF16_C64=mode)
+    switches(EDRL_BF16_K64=mode)
     bf = torch.bfloat16
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + Co)
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
