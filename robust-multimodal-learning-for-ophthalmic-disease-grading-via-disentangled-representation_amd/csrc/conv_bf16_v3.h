@@ -6,7 +6,11 @@
 // true when the geometry can run on the v3 core (channel counts, descriptor footprints) AND is expected to be faster there.
 bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad);
 // forward (dgrad = false) or data gradient (one parity class per call) of the plain bf16 convolution; honours GF_STATS / GF_ACCUM.
-int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st);
+// `fuse` (optional, data gradient only): fuse->ep_x != NULL selects the BatchNorm-backward epilogue (result masked with the ReLU
+// decision of the BatchNorm below, partial sums to fuse->ep_part; see the kernel); gather_bf16_v3_epi_ok checks its operands.
+bool gather_bf16_v3_epi_ok(const GatherGeom& g, const GatherFuse& F);
+int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st,
+                          const GatherFuse* fuse = nullptr);
 
 // Plain bf16 weight gradient on the 256x256 LDS-DMA core (conv_wgrad_bf16_v3.hip): writes `*splits_out` fp32 partial slabs
 // [split][Co][KH*KW*Ci] into `workspace`; the caller reduces them (splitk_reduce_h_kernel).

@@ -50,9 +50,15 @@ __device__ __forceinline__ int v3_swz(int r) {
   return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
 }
 
-template <bool DGRAD, int DBG = 0, bool STAGGER = false, int PRIO = 2>
+// EPI 1 (data gradient only): the result is the gradient of a BatchNorm(+ReLU) output -- it is (accumulated into dst when GF_ACCUM,
+// then) masked with that BatchNorm's ReLU decision (sign bytes F.ep_mask [pixel][NC/4], or recomputed from the raw tensor F.ep_x
+// with F.ep_fcoef when GF_EPI_RELU), stored, and the partial sums (sum g, sum g*(x - mean)) of every 128-row chunk go to
+// F.ep_part [F.ep_chunk0 + row / 128][2][NC] -- the layout the 128-row kernel's epilogue emits (conv_bf16.hip EPI 1), so the
+// BatchNorm backward of the wide residual stages needs no reduction pass of its own over the gradient.
+template <bool DGRAD, int DBG = 0, bool STAGGER = false, int PRIO = 2, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf16* __restrict__ src, const __bf16* __restrict__ wm,
-                                                                     __bf16* __restrict__ dst, GatherGeom g, int tiles_n) {
+                                                                     __bf16* __restrict__ dst, GatherGeom g, int tiles_n,
+                                                                     GatherFuse F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = 8, TN = 4;                 // wave tile 128 pixels x 64 channels of 16x16 MFMA tiles
   unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};  // DBG 4 only: s_memtime at entry / loop start / loop end / kernel end, s_memrealtime at entry / end
@@ -341,7 +347,94 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
     }
   }
   __syncthreads();
-  {
+  if constexpr (EPI != 0) {
+    const bool accum = g.flags & GF_ACCUM;
+    const int rr = tid >> 5, c = tid & 31;
+    const int n = n0 + c * 8;                       // (NC % 256 == 0: every column of the tile exists)
+    const int nq = g.NC >> 2;
+    const __bf16* epx = reinterpret_cast<const __bf16*>(F.ep_x);
+    const bool use_mask = F.ep_mask != nullptr;
+    const bool use_relu = !use_mask && (g.flags & GF_EPI_RELU);
+    float em[8], esc[8], esh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      em[e] = F.ep_fcoef[n + e];
+      esc[e] = use_relu ? F.ep_fcoef[2 * (long)g.NC + n + e] : 0.f;
+      esh[e] = use_relu ? F.ep_fcoef[4 * (long)g.NC + n + e] : 0.f;
+    }
+    float s0[2][8], s1[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s0[h][e] = s1[h][e] = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                   // chunk h of the tile = rows 128 h .. 128 h + 127
+      long pixs[8];
+      bf16x8 opre[8], xpre[8];
+      unsigned mb[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                 // all global operands of the chunk requested up front
+        const long m = m0 + (h * 8 + i) * 16 + rr;
+        long pix = m;
+        if (g.step > 1 && m < g.M) {
+          const int nn = (int)(m / ohw);
+          const int rem = (int)(m - (long)nn * ohw);
+          const int ii = rem / g.OWs, jj = rem - ii * g.OWs;
+          pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+        }
+        pixs[i] = m < g.M ? pix : -1;
+        mb[i] = 0xffu;
+        if (pixs[i] >= 0) {
+          xpre[i] = *reinterpret_cast<const bf16x8*>(epx + pix * F.ld_ep + n);
+          if (accum) opre[i] = *reinterpret_cast<const bf16x8*>(dst + pix * g.ld_dst + n);
+          if (use_mask) mb[i] = *reinterpret_cast<const unsigned short*>(F.ep_mask + pix * nq + (n >> 2));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (pixs[i] >= 0) {
+          const int row = (h * 8 + i) * 16 + rr;
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * 512 + ((c ^ rr) << 4));
+          bf16x8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float vf = (float)v[e];
+            if (accum) vf += (float)opre[i][e];
+            const float xe = (float)xpre[i][e];
+            const bool keep = use_mask ? ((mb[i] >> e) & 1u) != 0u : (use_relu ? __builtin_fmaf(xe, esc[e], esh[e]) > 0.f : true);
+            vf = keep ? vf : 0.f;
+            s0[h][e] += vf;
+            s1[h][e] = __builtin_fmaf(vf, xe - em[e], s1[h][e]);
+            ov[e] = (__bf16)vf;
+          }
+          *reinterpret_cast<bf16x8*>(dst + pixs[i] * g.ld_dst + n) = ov;
+        }
+      }
+    }
+    __syncthreads();                                // every wave is done with the tile image: its LDS becomes the reduction scratch
+    float* red = reinterpret_cast<float*>(smem);    // [chunk][plane][wave][256 channels]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s0[h][e] += __shfl_xor(s0[h][e], 32, 64); s1[h][e] += __shfl_xor(s1[h][e], 32, 64); }
+    if (lane < 32) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[((h * 2 + 0) * 8 + wave) * 256 + c * 8 + e] = s0[h][e];
+          red[((h * 2 + 1) * 8 + wave) * 256 + c * 8 + e] = s1[h][e];
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < 1024; o += 512) {         // ordered sum over the 8 waves: deterministic
+      const int h = o >> 9, pl = (o >> 8) & 1, ch = o & 255;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[((h * 2 + pl) * 8 + w) * 256 + ch];
+      if (m0 + h * 128 < g.M) F.ep_part[((long)F.ep_chunk0 + 2 * tile_m + h) * 2 * g.NC + (long)pl * g.NC + n0 + ch] = t;
+    }
+  } else {
     const bool accum = g.flags & GF_ACCUM;
     const int rr = tid >> 5, c = tid & 31;
     const int n = n0 + c * 8;
@@ -403,25 +496,41 @@ bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad) {
   return g.M >= 256 * 64 && g.Ktot >= (dgrad ? 128 : kmin_f);
 }
 
-int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st) {
+bool gather_bf16_v3_epi_ok(const GatherGeom& g, const GatherFuse& F) {
+  return F.ep_x && F.ep_fcoef && F.ep_part && (F.ld_ep % 8 == 0) && !((uintptr_t)F.ep_x & 15) && !((uintptr_t)F.ep_mask & 1) &&
+         (g.NC % 8 == 0);
+}
+
+int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st,
+                          const GatherFuse* fuse) {
   const int tiles_m = edrl_cdiv(g.M, V3_BM), tiles_n = edrl_cdiv(g.NC, V3_BN);
   const long nblk = (long)tiles_m * tiles_n;
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   if (((uintptr_t)src & 15) || ((uintptr_t)wm & 15) || ((uintptr_t)dst & 15)) return EDRL_EINVAL;
-  static bool attr_set[2] = {false, false};
+  static bool attr_set[3] = {false, false, false};
+  GatherFuse F;
+  memset(&F, 0, sizeof(F));
+  if (fuse && fuse->ep_x) {      // data gradient with the BatchNorm-backward epilogue (mask + partial sums)
+    if (!dgrad || !gather_bf16_v3_epi_ok(g, *fuse)) return EDRL_EINVAL;
+    auto ke = conv_gather_bf16_v3_kernel<true, 0, false, 2, 1>;
+    if (!attr_set[2]) { (void)hipFuncSetAttribute((const void*)ke, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[2] = true; }
+    hipLaunchKernelGGL(ke, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, *fuse);
+    EDRL_LAUNCH_CHECK();
+    return 0;
+  }
   // EDRL_V3_STAGGER=1: the staggered variant (A/B switch; measured 0-4 % slower than the plain order, see the kernel comment)
   if (edrl_cfg().v3_stagger == 1) {
     auto ks = dgrad ? conv_gather_bf16_v3_kernel<true, 0, true> : conv_gather_bf16_v3_kernel<false, 0, true>;
     (void)hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-    hipLaunchKernelGGL(ks, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);
+    hipLaunchKernelGGL(ks, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, F);
     EDRL_LAUNCH_CHECK();
     return 0;
   }
   if (dgrad) {
     auto kern = conv_gather_bf16_v3_kernel<true>;
     if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[1] = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, F);
   } else {
 #ifdef EDRL_DIAG
     // Diagnostic builds (wrong or absent outputs by construction): compiled only into libedrl_hip_diag.so (make diag), never into
@@ -432,14 +541,14 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
       (void)hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
       GatherGeom gd = g;
       if (dbg == 4) { gd.stat_shift = (const float*)g.stat_part; gd.flags &= ~GF_STATS; }     // stamps go to the caller's partials buffer
-      hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, gd, tiles_n);
+      hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, gd, tiles_n, F);
       EDRL_LAUNCH_CHECK();
       return 0;
     }
 #endif
     auto kern = conv_gather_bf16_v3_kernel<false>;
     if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[0] = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, F);
   }
   EDRL_LAUNCH_CHECK();
   return 0;

@@ -185,6 +185,7 @@ class _K32:
     apply_res_name, reduce_name, elt = "edrl_bn_apply_res_f32", "edrl_bn_bwd_reduce_f32", 4.0
     fuse_max_planes = 1 << 30        # every residual stage takes the fused-BatchNorm path
     mid_sep = False                  # (bf16 only) the 3x3 layer of a fused bottleneck block on the plain kernels
+    wide_sep = False                 # (bf16 only) see _KBF16
     grad_in = staticmethod(lambda dout: dout.contiguous())
     feat_out = staticmethod(lambda cur: cur)
 
@@ -294,6 +295,14 @@ class _KBF16:
     # materialised by edrl_bn_draw_bf16, plain weight / data gradient, and the standalone reduce that hands the masked gradient
     # and the partial sums back to the fused chain (stride-1 blocks; the stride-2 block's reduce runs on the 4x larger map).
     mid_sep = os.environ.get("EDRL_BF16_MID_SEP", "1") != "0"
+    # Bottleneck blocks ABOVE fuse_max_planes (stages 3-4: MFMA-bound layers on the 256x256 LDS-DMA cores, whose operands come by
+    # DMA and cannot be transformed in registers) keep materialised activations and d_raw tensors, but their BatchNorm BACKWARD
+    # statistics ride on the data gradients like in the fused blocks: every data-gradient kernel masks its result with the sign
+    # bytes of the BatchNorm below and emits (sum g, sum g*(x - mean)) from its epilogue (conv_bf16_v3.hip EPI 1), d_raw =
+    # A*g + nK2*x + C2 is then ONE pass (edrl_bn_draw_bf16).  Per conv -> BN unit this drops the reduction pass over (dout, raw,
+    # mask) and the separate dres tensor of the block's last BatchNorm; the block output comes from bn_apply_res as in a fused block,
+    # so the gradient hand-over between blocks stays ("masked", g, partials).  EDRL_BF16_WIDE_SEP=0: the separate passes of round 3.
+    wide_sep = os.environ.get("EDRL_BF16_WIDE_SEP", "1") != "0"
     grad_in = staticmethod(lambda dout: ops.to_bf16(dout.contiguous()))
     feat_out = staticmethod(lambda cur: ops.to_f32(cur))
 
@@ -422,8 +431,11 @@ class _TrunkFn(torch.autograd.Function):
             N, H, W, Ci = cur.shape
             s = blk["stride"]
             pl = p[blk["name"] + ".conv1.weight"].shape[0]
+            mode = "fused"
             if pl > K.fuse_max_planes:       # kernel-set policy (see _KBF16)
-                return False
+                if not (K.wide_sep and T.kind == "bottleneck" and cap is None):
+                    return False
+                mode = "wide"
             Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
             if T.kind == "bottleneck":
                 geo = [(H, W, Ci, pl, 1, 1, 0), (H, W, pl, pl, 3, s, 1), (Ho, Wo, pl, 4 * pl, 1, 1, 0)]
@@ -433,7 +445,16 @@ class _TrunkFn(torch.autograd.Function):
                 co = pl
             if blk["downsample"]:
                 geo.append((H, W, Ci, co, 1, s, 0))
-            return all(K.fused_ok(N, h, w, ci, c_o, k, st, pd) for h, w, ci, c_o, k, st, pd in geo)
+            return mode if all(K.fused_ok(N, h, w, ci, c_o, k, st, pd) for h, w, ci, c_o, k, st, pd in geo) else False
+
+        def bn_act(raw, fc):
+            """(wide blocks) materialised activation relu(bn(raw)) + its sign bytes, one elementwise pass."""
+            C = raw.shape[-1]
+            M = raw.numel() // C
+            act = torch.empty_like(raw)
+            kb = torch.empty((M, C // 4), device=raw.device, dtype=torch.uint8)
+            L.call("edrl_bn_apply_mx", P(raw), 1, P(fc[0]), P(fc[2]), P(fc[3]), None, P(act), 1, P(kb), M, C, 1)
+            return act, kb
 
         p0, saved["stem"] = K.stem_fwd(T, x, p, bnd, cap, cb)
         cur = p0
@@ -444,14 +465,23 @@ class _TrunkFn(torch.autograd.Function):
             # rebuilds from the raw tensors (see get_x in backward) -- it is not kept
             rec = {"x": None if (T.recompute_out and prev_fused and cap is None) else cur}
             prev_fused = False
-            if block_fused_ok(blk, cur):
+            bmode = block_fused_ok(blk, cur)
+            if bmode:
                 rec["fused"] = True
                 prev_fused = True
                 cd = fd = None
                 if blk["downsample"]:
                     cd, fd = cf(pre + ".downsample.0", pre + ".downsample.1", cur, None, s, 0)
                     rec.update(cd=cd, fd=fd)
-                if T.kind == "bottleneck":
+                if bmode == "wide":
+                    c1, f1 = cf(pre + ".conv1", pre + ".bn1", cur, None, 1, 0)
+                    a1, k1 = bn_act(c1, f1)
+                    c2, f2 = cf(pre + ".conv2", pre + ".bn2", a1, None, s, 1)
+                    a2, k2 = bn_act(c2, f2)
+                    cl, fl = cf(pre + ".conv3", pre + ".bn3", a2, None, 1, 0)
+                    rec.update(wide=True, c1=c1, f1=f1, a1=a1, k1=k1, c2=c2, f2=f2, a2=a2, k2=k2, c3=cl, f3=fl)
+                    last = pre + ".conv3"
+                elif T.kind == "bottleneck":
                     c1, f1 = cf(pre + ".conv1", pre + ".bn1", cur, None, 1, 0)
                     if K.mid_sep and s == 1:
                         C1 = c1.shape[-1]
@@ -660,6 +690,51 @@ class _TrunkFn(torch.autograd.Function):
                     _, gl, part, chunks, planes = grad_in
                 bl = fin_bwd(last_bn, part, chunks, planes, cl, fl)
                 c1, f1 = rec["c1"], rec["f1"]
+                if rec.get("wide"):
+                    # materialised d_raw per unit (one pass), plain weight / data gradients on the LDS-DMA cores, the BatchNorm
+                    # backward statistics from the data gradients' epilogues (sign bytes of the BatchNorm below)
+                    def draw(g_, raw_, bc_):
+                        Cc = raw_.shape[-1]
+                        d_ = torch.empty_like(raw_)
+                        L.call("edrl_bn_draw_bf16", P(g_), P(raw_), P(bc_), P(d_), raw_.numel() // Cc, Cc)
+                        return d_
+
+                    def wg(name, d_, inp, st_, pd_):
+                        grads[name + ".weight"] = K.conv_wgrad(d_, inp, tuple(p[name + ".weight"].shape), st_, pd_)
+
+                    c2, f2 = rec["c2"], rec["f2"]
+                    d3 = draw(gl, cl, bl)
+                    wg(last, d3, rec["a2"], 1, 0)
+                    g2, part, chunks = K.dgrad_bn(d3, None, None, wt_of(last), tuple(c2.shape), 1, 0, ep=(c2, rec["k2"], f2, True))
+                    del d3
+                    b2 = fin_bwd(pre + ".bn2", part, chunks, 2, c2, f2)
+                    d2 = draw(g2, c2, b2)
+                    del g2
+                    wg(pre + ".conv2", d2, rec["a1"], s, 1)
+                    g1, part, chunks = K.dgrad_bn(d2, None, None, wt_of(pre + ".conv2"), tuple(c1.shape), s, 1,
+                                                  ep=(c1, rec["k1"], f1, True))
+                    del d2
+                    b1 = fin_bwd(pre + ".bn1", part, chunks, 2, c1, f1)
+                    d1 = draw(g1, c1, b1)
+                    del g1
+                    wg(pre + ".conv1", d1, xin, 1, 0)
+                    if blk["downsample"]:
+                        cd, fd = rec["cd"], rec["fd"]
+                        _, partd, chunksd, planesd = _bn_bwd_reduce(K, gl, None, cd, fd, want_g=False)
+                        bd = fin_bwd(pre + ".downsample.1", partd, chunksd, planesd, cd, fd)
+                        dd = draw(gl, cd, bd)
+                        wg(pre + ".downsample.0", dd, xin, s, 0)
+                        dx = K.conv_dgrad(dd, wt_of(pre + ".downsample.0"), tuple(xin.shape), s, 0)     # full cover (zero fill off-lattice)
+                        del dd
+                    else:
+                        dx = gl
+                    if ep_lo is not None:
+                        r = K.dgrad_bn(d1, None, None, wt_of(pre + ".conv1"), tuple(xin.shape), 1, 0, out=dx, accumulate=True, ep=ep_lo)
+                        grad_in = ("masked", r[0], r[1], r[2], 2)
+                    else:
+                        grad_in = ("plain", K.conv_dgrad(d1, wt_of(pre + ".conv1"), tuple(xin.shape), 1, 0, out=dx, accumulate=True))
+                    del rec, saved[pre]
+                    continue
                 if bott:
                     c2, f2 = rec["c2"], rec["f2"]
                     fwgrad(last, gl, cl, bl, c2, f2, 1, 0)

@@ -704,3 +704,85 @@ def test_fused_bn_backward_large_mean_bf16(edrl, dev, geom, c64, switches):
     err = ((nchw(d_raw.double().cpu()) - dx_ref) * care).abs().max() / dx_ref.abs().max()
     print(f"[parity] bf16 large-mean d_raw {geom}: max-rel-err {err:.3e} (tol {2 ** -7:.1e})")
     assert err <= 2 ** -7
+
+
+V3_EPI_CASES = [
+    # N, Hi, Wi, Ci (dx channels, multiple of 256), Co, k, s, p, accumulate, sign bytes?
+    (3, 14, 14, 256, 256, 3, 1, 1, False, True),
+    (3, 14, 14, 256, 256, 3, 1, 1, False, False),      # decision recomputed from the raw tensor
+    (2, 13, 11, 512, 256, 1, 1, 0, True, True),        # block-input gradient: accumulate, then mask
+    (2, 13, 11, 256, 512, 3, 2, 1, False, True),       # stride-2 parity classes, ragged class sizes
+    (1, 7, 7, 256, 256, 3, 1, 1, False, True),         # less than one 128-row chunk
+    (5, 9, 7, 256, 1024, 1, 1, 0, True, False),
+    (2, 12, 12, 512, 256, 1, 2, 0, True, True),        # 1x1 stride 2: three of the four classes have no tap (epilogue only)
+]
+
+
+@pytest.mark.parametrize("case", V3_EPI_CASES)
+def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, switches):
+    """The BatchNorm-backward epilogue of the 256x256 LDS-DMA data-gradient core (conv_bf16_v3.hip EPI 1: accumulate, mask with
+    the sign bytes / the recomputed ReLU decision of the BatchNorm below, (sum g, sum g*(x - mean)) per 128-row chunk), forced on
+    far below its production sizes: the masked gradient against fp64 at one bf16 ulp (two with accumulate), every chunk's partial
+    sums against fp64 sums over the STORED gradient (the kernel sums the values it stores before their final rounding: 2^-8 of
+    sum |g|), and both against the 128-row kernel's epilogue (same chunk layout: one finalize serves either)."""
+    ops = edrl.ops
+    N, H, W, Ci, Co, k, s, p, accum, use_mask = case
+    g = torch.Generator().manual_seed(31 + Ci + Co)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    w = (torch.randn(Co, k, k, Ci, generator=g) * 0.1).bfloat16()
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).bfloat16()
+    xraw = torch.randn(N, H, W, Ci, generator=g).bfloat16()
+    old = torch.randn(N, H, W, Ci, generator=g).bfloat16()
+    fc = torch.empty(5, Ci)
+    fc[0] = 0.3 * torch.randn(Ci, generator=g); fc[1].fill_(1.0); fc[2] = 0.5 + torch.rand(Ci, generator=g)
+    fc[3] = 0.2 * torch.randn(Ci, generator=g); fc[4] = fc[3] - fc[0] * fc[2]
+    pre = xraw.float() * fc[2] + fc[4]
+    keep = pre > 0
+    mask = None
+    if use_mask:
+        keep = torch.rand(N, H, W, Ci, generator=g) < 0.6
+        mask = (keep.reshape(N * H * W, Ci // 4, 4).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8)).sum(-1).to(torch.uint8)
+    xd = torch.zeros(N, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, w.double().permute(0, 3, 1, 2), stride=s, padding=p).backward(nchw(dy.double()))
+    full = xd.grad.permute(0, 2, 3, 1) + (old.double() if accum else 0.0)
+    ref = full * keep.double()
+    care = torch.ones_like(keep) if use_mask else (pre.abs() > 1e-6 * pre.abs().max())
+    wt = ops.permute_weight_bf16(w.float().to(dev))
+    outs = {}
+    for mode in ("0", "2"):
+        switches(EDRL_BF16_V3=mode)
+        dst = old.clone().to(dev) if accum else None
+        gm, part, chunks = ops.conv2d_dgrad_bn_bf16(dy.to(dev), None, None, wt, (N, H, W, Ci), s, p, out=dst, accumulate=accum,
+                                                    ep=(xraw.to(dev), mask.to(dev) if use_mask else None, fc.to(dev), True))
+        torch.cuda.synchronize()
+        outs[mode] = (gm.float().cpu(), part.cpu(), chunks)
+    gm, part, chunks = outs["2"]
+    tol = BF16_TOL * (2 if accum else 1)
+    err = ((gm.double() - ref) * care).abs().max() / ref.abs().max()
+    print(f"[parity] v3 dgrad epilogue {case}: masked gradient max-rel-err {err:.3e} (tol {tol:.1e})")
+    assert err <= tol
+    e2 = ((gm - outs["0"][0]).double() * care).abs().max() / ref.abs().max()
+    assert e2 <= tol, f"v3 vs 128-row kernel: {e2:.3e}"
+    assert chunks == outs["0"][2] and part.shape == outs["0"][1].shape
+    # chunk partial sums: rows of a parity class are numbered class by class, 128 per chunk
+    rows = []
+    for ph in range(s):
+        for pw in range(s):
+            h0, w0 = (ph - p) % s, (pw - p) % s
+            sub = gm[:, h0::s, w0::s, :]
+            subx = xraw[:, h0::s, w0::s, :].float()
+            if sub.numel() == 0:
+                continue
+            rows.append((sub.reshape(-1, Ci).double(), subx.reshape(-1, Ci).double()))
+    c = 0
+    for gr, xr in rows:
+        for r0 in range(0, gr.shape[0], 128):
+            gb, xb = gr[r0:r0 + 128], xr[r0:r0 + 128] - fc[0].double()
+            sc0 = max(float(gb.abs().sum(0).max()), 1e-6); sc1 = max(float((gb * xb).abs().sum(0).max()), 1e-6)
+            assert float((part[c, 0].double() - gb.sum(0)).abs().max()) <= 2 ** -8 * sc0, f"chunk {c} sum g"
+            assert float((part[c, 1].double() - (gb * xb).sum(0)).abs().max()) <= 2 ** -8 * sc1, f"chunk {c} sum g*(x-mean)"
+            c += 1
+    assert c == chunks
+    tot = lambda t: t.double().sum(0)
+    sc = ref.abs().sum(dim=(0, 1, 2)).max()
+    assert float((tot(part)[0] - tot(outs["0"][1])[0]).abs().max() / sc) < 2e-3, "sum g: v3 vs 128-row epilogue"
