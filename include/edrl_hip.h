@@ -59,6 +59,14 @@ int edrl_conv2d_nhwc_fwd_stats_f32_obf16(const float* x, const float* w, void* y
                                          int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride,
                                          int pad, hipStream_t stream);
 
+/* The same stem for the 1-channel (OCT) bf16 trunk on the bf16 matrix pipe: xs = the 2x2 space-to-depth image fp32 [N,Hs,Ws,4]
+ * (edrl_space_to_depth2_f32), w = the folded 4x4x4 weights as bf16 [64][64] (edrl_stem_weight_fold_f32 + edrl_cast_f32_to_bf16);
+ * image and weights are rounded to bf16 in registers, fp32 accumulate, y bf16 [N,Hs,Ws,64], BatchNorm chunk partials
+ * [ceil(N*Hs*Ws/128)][3][64] from the fp32 accumulators (stat_part may be NULL).  Streaming kernel: 0.4 GB in, 3.3 GB out per
+ * 2048 224x224 slices (fusion_net.py:885 encoder slot, config C2/C4). */
+int edrl_stem_conv_s2d_bf16(const float* xs, const void* w_bf16, void* y_bf16, float* stat_part, size_t stat_part_bytes, int N, int Hs,
+                            int Ws, hipStream_t stream);
+
 /* Data gradient (autograd of the above): dx [+]= conv_transpose(dy, w).
  * wt is w permuted to [Ci,KH,KW,Co] by edrl_permute_weight_f32. */
 int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int Hi, int Wi, int Ci,

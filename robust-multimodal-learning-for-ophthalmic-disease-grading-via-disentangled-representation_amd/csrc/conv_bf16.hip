@@ -1187,6 +1187,15 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
   return 0;
 }
 
+// The 7x7 / stride 2 / pad 3 stem of a 1-channel bf16 trunk as a bf16-MFMA streaming kernel (conv_c64_bf16.hip, ATR 2).
+int edrl_stem_conv_s2d_bf16(const float* xs, const void* w, void* y, float* stat_part, size_t stat_part_bytes, int N, int Hs, int Ws,
+                            hipStream_t st) {
+  if (!xs || !w || !y || !stem_s2d_bf16_ok(N, Hs, Ws)) return EDRL_EINVAL;
+  const long M = (long)N * Hs * Ws;
+  if (stat_part && stat_part_bytes < (size_t)((M + 127) / 128) * 3 * 64 * sizeof(float)) return EDRL_ENOSPC;
+  return launch_stem_s2d_bf16(xs, w, y, N, Hs, Ws, stat_part, st);
+}
+
 int edrl_conv2d_fused_ok_bf16(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad) {
   if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || (Ci % HBK) || (Co % HBK) || (stride != 1 && stride != 2)) return 0;
   if ((long)N * Hi * Wi > 0x7fffffffL || (long)N * Ho * Wo > 0x7fffffffL) return 0;

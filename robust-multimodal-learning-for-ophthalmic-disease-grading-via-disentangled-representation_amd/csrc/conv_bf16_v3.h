@@ -30,3 +30,8 @@ int launch_conv3x3_c64(const void* src, const void* w, int flip, void* dst, int 
 bool conv1x1_k64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride, int pad);
 int launch_conv1x1_k64(const void* x, const float* in_fcoef, const void* w, void* y, int N, int H, int W, int Ci, int Co,
                        float* stat_part, hipStream_t st);
+
+// Stem of the 1-channel bf16 trunk on the streaming kernel of conv_c64_bf16.hip (ATR 2): 4x4 / pad 2 convolution over the fp32
+// space-to-depth image, operands rounded to bf16 in registers, bf16 MFMA, fp32 accumulate, bf16 output + BatchNorm chunk partials.
+bool stem_s2d_bf16_ok(int N, int Hs, int Ws);
+int launch_stem_s2d_bf16(const float* xs, const void* w, void* y, int N, int Hs, int Ws, float* stat_part, hipStream_t st);

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
           pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
         }
         pixs[i] = m < g.M ? pix : -1;
-        mb[i] = 0xffu;
+        mb[i] = 0xffffu;
         if (pixs[i] >= 0) {
           xpre[i] = *reinterpret_cast<const bf16x8*>(epx + pix * F.ld_ep + n);
           if (accum) opre[i] = *reinterpret_cast<const bf16x8*>(dst + pix * g.ld_dst + n);
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3_kernel(const __bf1
             float vf = (float)v[e];
             if (accum) vf += (float)opre[i][e];
             const float xe = (float)xpre[i][e];
-            const bool keep = use_mask ? ((mb[i] >> e) & 1u) != 0u : (use_relu ? __builtin_fmaf(xe, esc[e], esh[e]) > 0.f : true);
+            const bool keep = use_mask ? ((mb[i] >> ((e & 3) + 8 * (e >> 2))) & 1u) != 0u :      // two sign bytes, 4 channels each
+                                        (use_relu ? __builtin_fmaf(xe, esc[e], esh[e]) > 0.f : true);
             vf = keep ? vf : 0.f;
             s0[h][e] += vf;
             s1[h][e] = __builtin_fmaf(vf, xe - em[e], s1[h][e]);

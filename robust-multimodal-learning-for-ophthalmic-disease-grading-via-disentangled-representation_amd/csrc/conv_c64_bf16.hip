@@ -311,10 +311,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_bf16_kernel(const __bf16* 
 // full by the 8 independent waves per CU.
 // KS = K / 32: 2 (64 input channels: 8 waves, two per SIMD) or 4 (128 input channels, `layer2.*.conv3`: the chunk's fragments are 128
 // registers, so 4 waves per workgroup, one per SIMD with the whole register file; the weights of 512 x 128 fill 128 KiB of LDS).
+// ATR 2 (KS = 2, NC = 64): the STEM of the bf16 trunks' 1-channel (OCT) encoder.  The 7x7 / stride 2 / pad 3 convolution is a
+// 4x4 / stride 1 / pad 2 convolution over the 2x2 space-to-depth image xs [N][Hs][Ws][4] fp32 (edrl_space_to_depth2_f32,
+// edrl_stem_weight_fold_f32): K = 4 window rows x 16 contiguous floats = 64.  `src` is that fp32 image; a lane's fragment of K step
+// ks is half a window row -- 8 consecutive floats (two image columns x 4 channels), rounded to bf16 in registers; window rows /
+// columns outside the image are zeros.  Same streaming skeleton as the 1x1 layers: 1.6 KiB of image in, 16 KiB out per 128 pixels.
+struct StemGeom {
+  int Hs, Ws;
+  unsigned mg_w, mg_h;     // x / d == (x * mg) >> sh for x < 2^31 (conv_geom.h gather_magic)
+  int sh_w, sh_h;
+};
+
 template <int ATR, int KS>
 __global__ __launch_bounds__(KS == 2 ? 512 : 256, KS == 2 ? 2 : 1) void conv1x1_k64_bf16_kernel(
     const __bf16* __restrict__ src, const __bf16* __restrict__ w, __bf16* __restrict__ dst, int M, int NC, int nchunks,
-    const float* __restrict__ fcoef, float* __restrict__ stat_part) {
+    const float* __restrict__ fcoef, float* __restrict__ stat_part, StemGeom sg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int KC = 32 * KS;                    // input channels
   constexpr int NW = KS == 2 ? 8 : 4;            // waves per workgroup
@@ -347,12 +358,38 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, KS == 2 ? 2 : 1) void conv1x1_
     const int m0 = chunk * 128;
     // ---- the chunk's pixel fragments: 8 column tiles x KS K steps, 16 bytes per lane each
     c64_bf16x8 a[8][KS];
+    if constexpr (ATR == 2) {
+      const float* xs = reinterpret_cast<const float*>(src);
+#pragma unroll
+      for (int pt = 0; pt < 8; ++pt) {
+        const int m = m0 + 16 * pt + pl;
+        const unsigned r = (unsigned)(((unsigned long long)(unsigned)m * sg.mg_w) >> sg.sh_w);      // m / Ws = n * Hs + oh
+        const int ow = m - (int)r * sg.Ws;
+        const unsigned nimg = (unsigned)(((unsigned long long)r * sg.mg_h) >> sg.sh_h);
+        const int oh = (int)r - (int)nimg * sg.Hs;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int qp = 4 * ks + gq;                       // k chunk of 8: window row qp >> 1, columns 2 (qp & 1), 2 (qp & 1) + 1
+          const int ih = oh - 2 + (qp >> 1), iw = ow - 2 + 2 * (qp & 1);
+          const bool rowok = m < M && (unsigned)ih < (unsigned)sg.Hs;
+          const float* pp = xs + ((long)((int)nimg * sg.Hs + ih) * sg.Ws + iw) * 4;
+          f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+          if (rowok && (unsigned)iw < (unsigned)sg.Ws) lo = *reinterpret_cast<const f32x4*>(pp);
+          if (rowok && (unsigned)(iw + 1) < (unsigned)sg.Ws) hi = *reinterpret_cast<const f32x4*>(pp + 4);
+          c64_bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+          a[pt][ks] = o;
+        }
+      }
+    } else {
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {
       const int m = m0 + 16 * pt + pl;
       const long mo = (long)(m < M ? m : M - 1) * KC;            // (rows past the end: a valid address, results never stored)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) a[pt][ks] = *reinterpret_cast<const c64_bf16x8*>(src + mo + 32 * ks + 8 * gq);
+    }
     }
     if constexpr (ATR == 1) {
 #pragma unroll
@@ -465,7 +502,7 @@ bool conv1x1_k64_ok(int N, int H, int W, int Ci, int Co, int KH, int KW, int str
 
 template <int ATR, int KS>
 static void launch_k64_impl(const void* x, const float* in_fcoef, const void* w, void* y, long M, int Co, int nchunks, float* stat_part,
-                            hipStream_t st) {
+                            hipStream_t st, StemGeom sg = StemGeom{0, 0, 0u, 0u, 0, 0}) {
   constexpr int NW = KS == 2 ? 8 : 4;
   int grid = (nchunks + NW - 1) / NW;
   if (grid > 256) grid = 256;
@@ -474,7 +511,7 @@ static void launch_k64_impl(const void* x, const float* in_fcoef, const void* w,
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * KS * 2 + 1024); attr = true; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, (const __bf16*)x, (const __bf16*)w, (__bf16*)y, (int)M, Co, nchunks,
-                     in_fcoef, stat_part);
+                     in_fcoef, stat_part, sg);
 }
 
 // y [M][Co] = conv1x1(x [M][Ci] (ATR: relu(x*scale + shift2) with in_fcoef [5][Ci]), w [Co][Ci]), Ci = 64 | 128; stat_part optional.
@@ -490,6 +527,23 @@ int launch_conv1x1_k64(const void* x, const float* in_fcoef, const void* w, void
     if (in_fcoef) launch_k64_impl<1, 4>(x, in_fcoef, w, y, M, Co, nchunks, stat_part, st);
     else launch_k64_impl<0, 4>(x, in_fcoef, w, y, M, Co, nchunks, stat_part, st);
   }
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Stem of a 1-channel bf16 trunk (kernel comment, ATR 2): xs fp32 [N][Hs][Ws][4] (space-to-depth image), w bf16 [64][64] (folded
+// 4x4x4 weights, k = (window row, column, channel)), y bf16 [N][Hs][Ws][64], stat_part [ceil(M/128)][3][64] optional.
+bool stem_s2d_bf16_ok(int N, int Hs, int Ws) {
+  return N > 0 && Hs >= 2 && Ws >= 2 && (long)N * Hs * Ws < 0x7fffff00L && (long)N * Hs * Ws * 16 < (1L << 40);
+}
+int launch_stem_s2d_bf16(const float* xs, const void* w, void* y, int N, int Hs, int Ws, float* stat_part, hipStream_t st) {
+  if (!stem_s2d_bf16_ok(N, Hs, Ws) || ((uintptr_t)xs & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return EDRL_EINVAL;
+  const long M = (long)N * Hs * Ws;
+  StemGeom sg;
+  sg.Hs = Hs; sg.Ws = Ws;
+  gather_magic((unsigned)Ws, &sg.mg_w, &sg.sh_w);
+  gather_magic((unsigned)Hs, &sg.mg_h, &sg.sh_h);
+  launch_k64_impl<2, 2>(xs, nullptr, w, y, M, 64, (int)((M + 127) / 128), stat_part, st, sg);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

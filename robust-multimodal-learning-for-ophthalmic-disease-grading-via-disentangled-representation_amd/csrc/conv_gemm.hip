@@ -609,7 +609,12 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     // Vector epilogue: each wave transposes its accumulators through LDS (the K-loop buffers are free now) so that a
     // lane owns 4 consecutive channels of one pixel: 16-B stores, 16 lanes per 256-B row segment, instead of 64
     // scalar stores per lane.  Bias / ReLU / mask / accumulate are applied on the float4.
-    constexpr int SLD = WN + 4;            // padded staging row (floats)
+    // Staging row stride = WN floats, NO padding: the hardware's ds_read_b128 lane groups ({0-3,12-15,20-27}, ...:
+    // MI355X_MICROARCH.md, LDS) are built so that a LINEAR image with 256-byte (64-float) or 128-byte rows is conflict-free, and
+    // the ds_write_b32 transposing stores bank per 32-lane half (consecutive floats: conflict-free at any stride).  The WN + 4
+    // padding of rounds 1-3 (a CUDA habit) put row r + 1's float4 slots onto row r's banks for two lanes of every group:
+    // 32 % of this kernel's LDS-active cycles were bank conflicts (profiles/r03_pmc_traffic_c1.json).
+    constexpr int SLD = WN;
     constexpr int C4 = WN / 4;             // float4 per staged row
     constexpr int RPP2 = 64 / C4;          // rows per pass of the wave
     float* stage = smem + wave * 32 * SLD;

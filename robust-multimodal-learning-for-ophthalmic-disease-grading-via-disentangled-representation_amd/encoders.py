@@ -116,6 +116,7 @@ def _bn_bwd(dout, mask, raw, mean, rstd, gamma, want_dres):
 # passes; the gradient handed from block to block is ("plain", dout) or ("masked", g, part, chunks, planes).
 _FUSE_BN = os.environ.get("EDRL_FUSE_BN", "1") != "0"
 _STEM_RAW16 = os.environ.get("EDRL_BF16_STEM_RAW16", "1") != "0"    # (bf16 trunk) raw stem conv output stored as bf16, statistics from the conv epilogue
+_STEM_BF16MMA = os.environ.get("EDRL_BF16_STEM_MMA", "1") != "0"   # (bf16 trunk, 1-channel input) stem conv on the bf16 matrix pipe
 _FUSE_STEM = os.environ.get("EDRL_FUSE_STEM", "1") != "0"      # BatchNorm + ReLU of the stem folded into its max-pool (fp32 trunk)
 
 
@@ -156,8 +157,16 @@ def _bn_bwd_reduce(K, dout, mask, raw, fcoef, want_g):
 
 
 def _dbg_act(raw, fc):
-    """(tests only) the activation a fused consumer forms on the fly: relu(x*scale + shift2)."""
-    return torch.relu(torch.addcmul(fc[4], raw, fc[2]))
+    """(tests only) the activation a fused consumer forms on the fly: relu(fma(x, scale, shift2)), ONE rounding.  Formed in fp64
+    and rounded once (x*scale is exact in fp64), so that the ReLU decisions handed to the decision-pinned oracle are the
+    kernels' own: torch.addcmul may round the product first, which flips the sign of a pre-activation within one ulp of zero --
+    one such element moved layer1.0.bn1.bias of the ResNet-50 step test by 2e-3 (tests/test_gpu_head.py, round 4)."""
+    return torch.clamp_min(_dbg_pre(raw, fc), 0.0)
+
+
+def _dbg_pre(raw, fc):
+    """(tests only) fma(x, scale, shift2) with the kernels' single rounding (see _dbg_act)."""
+    return torch.addcmul(fc[4].double(), raw.double(), fc[2].double()).float()
 
 
 def _dbg_draw(g, raw, bc):
@@ -251,7 +260,7 @@ class _K32:
                 da0 = torch.empty_like(raw)
                 L.call("edrl_maxpool3x3s2_bwd_f32", P(dcur), P(idx), P(da0), N, H, W, C)
                 cap["maxpool"].update(dout=dcur, dinp=da0)
-                g0 = da0 * (torch.addcmul(fc[4], raw, fc[2]) > 0)
+                g0 = da0 * (_dbg_pre(raw, fc) > 0)
                 cap["bwd:bn1"] = dict(dout=g0, dgamma=dg, dbeta=db, d_raw=draw, dres=None, masked=True)
                 cap["conv1"].update(d_raw=draw, dW=grads["conv1.weight"], dx_before=None, dx_after=None)
             return None
@@ -315,7 +324,12 @@ class _KBF16:
         if _FUSE_STEM and cap is None and _STEM_S2D and _STEM_RAW16:
             # the raw stem output is a bf16 tensor like every other layer's (fp32 image, fp32 MFMA, one rounding on the way out);
             # its statistics come from the conv epilogue's fp32 partials -- no separate statistics pass over the largest tensor
-            raw, part, chunks, x, folded = ops.stem_conv_fwd_obf16(x, p["conv1.weight"])
+            if _STEM_BF16MMA and x.shape[-1] == 1 and p["conv1.weight"].shape[0] == 64 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0:
+                # 1-channel (OCT) stem on the bf16 matrix pipe: image and weights rounded to bf16 in registers (EDRL_BF16_STEM_MMA=0:
+                # the fp32-MFMA stem of round 3, bf16 output only)
+                raw, part, chunks, x, folded = ops.stem_conv_fwd_bf16mma(x, p["conv1.weight"])
+            else:
+                raw, part, chunks, x, folded = ops.stem_conv_fwd_obf16(x, p["conv1.weight"])
             N, H, W, C = raw.shape
             M = N * H * W
             fc = _fcoef_from_partials(part, chunks, M, C, bn)
@@ -645,7 +659,7 @@ class _TrunkFn(torch.autograd.Function):
             return (raw_lo, kl, fc_lo, True), keep
 
         def recompute_keep(raw, fc):     # (tests) the pre-activation whose sign the epilogue re-derives
-            return lambda: torch.addcmul(fc[4], raw, fc[2])
+            return lambda: _dbg_pre(raw, fc)
 
         # ---- recompute mode (T.recompute_out): block outputs are rebuilt from the stored raw tensors, one elementwise pass
         # each (the forward's own edrl_bn_apply_res_f32, bit-identical), a residual stage at a time; out_j is dropped as soon

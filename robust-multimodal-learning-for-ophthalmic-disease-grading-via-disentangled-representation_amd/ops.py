@@ -236,6 +236,22 @@ def stem_conv_fwd_obf16(x, w):
     return out, part, chunks, xin, folded
 
 
+def stem_conv_fwd_bf16mma(x, w):
+    """The stem of the 1-channel bf16 trunk on the bf16 matrix pipe (edrl_stem_conv_s2d_bf16): x fp32 [N,H,W,1] with even H, W,
+    w fp32 [64,7,7,1].  -> (y bf16 [N,H/2,W/2,64], part, chunks, space-to-depth image kept for the weight gradient, True)."""
+    N, H, W, C = x.shape
+    assert C == 1 and w.shape[0] == 64 and tuple(w.shape[1:3]) == (7, 7) and H % 2 == 0 and W % 2 == 0
+    xs = space_to_depth2(x)
+    wk = to_bf16(stem_weight_fold(w))                      # [64,4,4,4] -> bf16 [64][64]
+    Hs, Ws = H // 2, W // 2
+    out = torch.empty((N, Hs, Ws, 64), device=x.device, dtype=torch.bfloat16)
+    chunks = L.query("edrl_conv_stats_chunks", N, Hs, Ws)
+    part = torch.empty((chunks, 3, 64), device=x.device, dtype=torch.float32)
+    _launch_timed("conv_gather_bf16", 2.0 * N * Hs * Ws * 64 * 49, "edrl_stem_conv_s2d_bf16", P(xs), P(wk), P(out), P(part),
+                  part.numel() * 4, N, Hs, Ws, nbytes=4.0 * xs.numel() + 2.0 * (wk.numel() + out.numel()))
+    return out, part, chunks, xs, True
+
+
 def stem_conv_wgrad(dy, x_saved, w_shape, folded):
     """dy fp32, or bf16 (the bf16 trunk's stem: fp32 x, dy widened on load)."""
     if not folded:

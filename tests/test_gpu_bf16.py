@@ -786,3 +786,34 @@ def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, switc
     tot = lambda t: t.double().sum(0)
     sc = ref.abs().sum(dim=(0, 1, 2)).max()
     assert float((tot(part)[0] - tot(outs["0"][1])[0]).abs().max() / sc) < 2e-3, "sum g: v3 vs 128-row epilogue"
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 32, 32), (2, 30, 34), (5, 8, 6), (1, 224, 224)])
+def test_stem_bf16_mma_kernel_vs_fp64_and_fp32_mfma_stem(edrl, dev, N, H, W):
+    """The 1-channel stem on the bf16 matrix pipe (edrl_stem_conv_s2d_bf16: 7x7/s2/p3 as a 4x4/p2 window over the space-to-depth
+    image, image and weights rounded to bf16 in registers).  Against the fp64 convolution of the SAME bf16-rounded image and weights
+    at one bf16 ulp of the output; BatchNorm chunk partials against sums over the kernel's own fp32 accumulators (via the stored
+    output: 2^-8); and against the fp32-MFMA stem of round 3 (unrounded operands) within the operand rounding, 2^-6 of the max."""
+    ops = edrl.ops
+    g = torch.Generator().manual_seed(N * 7 + H)
+    x = torch.rand(N, H, W, 1, generator=g)
+    w = torch.randn(64, 7, 7, 1, generator=g) * 0.1
+    xq, wq = x.bfloat16().double(), w.bfloat16().double()
+    ref = F.conv2d(xq.permute(0, 3, 1, 2), wq.permute(0, 3, 1, 2), stride=2, padding=3)
+    y, part, chunks, xs, folded = ops.stem_conv_fwd_bf16mma(x.to(dev), w.to(dev))
+    torch.cuda.synchronize()
+    assert folded and y.dtype == torch.bfloat16 and tuple(y.shape) == (N, H // 2, W // 2, 64)
+    check(f"bf16-MMA stem {N}x{H}x{W}", nchw(y.float().cpu()), ref, BF16_TOL)
+    y32, part32, chunks32, _, _ = ops.stem_conv_fwd_obf16(x.to(dev), w.to(dev))
+    check(f"bf16-MMA stem vs fp32-MFMA stem {N}x{H}x{W}", y.float().cpu(), y32.float().cpu(), 2.0 ** -6)
+    assert chunks == chunks32 == (N * (H // 2) * (W // 2) + 127) // 128
+    rows = ref.permute(0, 2, 3, 1).reshape(-1, 64)
+    M = rows.shape[0]
+    pv = part.cpu()
+    for c in range(0, chunks, max(1, chunks // 7)):
+        blk = rows[c * 128:min(M, (c + 1) * 128)]
+        K = pv[c, 2].double()
+        assert float((K - blk[0]).abs().max()) <= BF16_TOL * float(rows.abs().max()), "shift = the chunk's first row"
+        d = blk - K
+        assert float((pv[c, 0].double() - d.sum(0)).abs().max()) <= 1e-3 * max(float(d.abs().sum(0).max()), 1e-6), f"chunk {c} S1"
+        assert float((pv[c, 1].double() - (d * d).sum(0)).abs().max()) <= 1e-3 * max(float((d * d).sum(0).max()), 1e-6), f"chunk {c} S2"

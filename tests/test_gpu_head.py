@@ -269,7 +269,7 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high, depth, B, HW, S, fi
     check("step.loss_MDD", out["loss_MDD"].cpu().view(1), ref["loss_MDD"].view(1), 10 * tol)
     assert torch.equal(out["predicted"].cpu(), ref["predicted"])
     named = dict(m.named_parameters())
-    worst, nchk, worst_fro, fro_rows = 0.0, 0, 0.0, []
+    worst, nchk, worst_fro, fro_rows, failures = 0.0, 0, 0.0, [], []
     for n, r in ref["grads"].items():
         key = n
         if ".trunk." in n:      # the trunk registers its tensors with '.' -> '__'
@@ -299,14 +299,20 @@ def test_full_train_step_vs_oracle(edrl, dev, drop_oct_high, depth, B, HW, S, fi
             # encoder-trunk tensors (96-99 % of the step's MACs) bind at the 2e-3 of round 2 again: the 2.14e-3 that had it raised to
             # 5e-3 in round 3 was the unshifted sum g*x of the fused BatchNorm backward (fixed in round 4: sum g*(x - mean))
             fro_bound = 2e-3 if ".trunk." in n else 5e-3
-            assert fro < max(fro_bound, 3 * fro32), f"grad {n}: relative Frobenius error {fro:.3e} (fp32 oracle {fro32:.3e})"
-            assert e < max(2e-2, 3 * e32), f"grad {n}: worst element {e:.3e} (fp32 oracle {e32:.3e})"
+            if not fro < max(fro_bound, 3 * fro32):
+                failures.append(f"grad {n}: relative Frobenius error {fro:.3e} (fp32 oracle {fro32:.3e})")
+            if not e < max(2e-2, 3 * e32):
+                failures.append(f"grad {n}: worst element {e:.3e} (fp32 oracle {e32:.3e})")
             continue
         assert e < max(5e-3, min(10 * e32, 2e-2)), f"grad {n}: rel err {e:.3e} (fp32 envelope {e32:.3e})"
     for fro, fro32, n in sorted(fro_rows, reverse=True)[:6]:       # per-tensor attribution of the worst cases
         print(f"[parity]   {n}: relative Frobenius {fro:.3e} (fp32-CPU oracle {fro32:.3e})")
     for fro, fro32, n in sorted([r for r in fro_rows if ".trunk." in r[2]], reverse=True)[:4]:
         print(f"[parity]   worst trunk tensors: {n}: relative Frobenius {fro:.3e} (fp32-CPU oracle {fro32:.3e})")
+    if fixed and os.environ.get("EDRL_TEST_GRAD_TABLE"):      # full per-tensor table in network order (attribution runs)
+        for fro, fro32, n in fro_rows:
+            print(f"[gradtable] {n} {fro:.3e} {fro32:.3e}")
+    assert not failures, "; ".join(failures[:6])
     print(f"[parity] full step: {nchk} gradient tensors, worst rel err vs fp64 oracle {worst:.3e}"
           + (f", worst relative Frobenius {worst_fro:.3e}" if fixed else ""))
     # Adam moved every parameter that has a gradient
