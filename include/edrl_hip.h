@@ -67,6 +67,19 @@ int edrl_conv2d_nhwc_fwd_stats_f32_obf16(const float* x, const float* w, void* y
 int edrl_stem_conv_s2d_bf16(const float* xs, const void* w_bf16, void* y_bf16, float* stat_part, size_t stat_part_bytes, int N, int Hs,
                             int Ws, hipStream_t stream);
 
+/* Backward of an expanding 1x1 layer (Ci = 64 -> Co = 256, stride 1) inside a fused-BatchNorm block, both gradients from ONE pass
+ * over the two Co-wide tensors (the layer1.*.conv3 call sites of the bf16 trunk; replaces one edrl_conv2d_nhwc_wgrad_bn_bf16 + one
+ * edrl_conv2d_nhwc_dgrad_bn_bf16 call): d_raw = A*g + nK2*yraw + C2 (bcoef [4][Co]), X = relu(bn(x2raw; x2_fcoef [5][Ci])),
+ * dw [Co][Ci] fp32 = d_raw^T X (ordered split-K through `workspace`), g2 [N,H,W,Ci] bf16 = relu'(bn(x2raw)) * (d_raw wt^T) with
+ * wt = the permuted weights [Ci][Co] bf16, and the BatchNorm-backward partial sums (sum g2, sum g2*(x2raw - mean)) ->
+ * ep_part [edrl_conv1x1_k64_bwd_chunks][2][Ci] (planes = 2 for edrl_bn_bwd_finalize_partials_f32). */
+int edrl_conv1x1_k64_bwd_ok_bf16(int N, int H, int W, int Ci, int Co);
+long edrl_conv1x1_k64_bwd_chunks(int N, int H, int W);
+size_t edrl_conv1x1_k64_bwd_workspace_bytes(int N, int H, int W);
+int edrl_conv1x1_k64_bwd_bf16(const void* g, const void* yraw, const float* bcoef, const void* x2raw, const float* x2_fcoef,
+                              const void* wt, void* g2, float* ep_part, size_t ep_part_bytes, float* dw, float* workspace,
+                              size_t workspace_bytes, int N, int H, int W, int Ci, int Co, hipStream_t stream);
+
 /* Data gradient (autograd of the above): dx [+]= conv_transpose(dy, w).
  * wt is w permuted to [Ci,KH,KW,Co] by edrl_permute_weight_f32. */
 int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int Hi, int Wi, int Ci,

@@ -16,6 +16,7 @@ static void load(EdrlConfig& c) {
   c.bf16_wgrad_v3 = env_int("EDRL_BF16_WGRAD_V3", 1);
   c.bf16_c64 = env_int("EDRL_BF16_C64", 1);
   c.bf16_k64 = env_int("EDRL_BF16_K64", 1);
+  c.bf16_k64_bwd = env_int("EDRL_BF16_K64_BWD", 1);
   c.stem_pool_v8 = env_int("EDRL_STEM_POOL_V8", 1);
   c.bf16_epi_vw4 = env_int("EDRL_BF16_EPI_VW4", 0);
   c.bf16_ktail = env_int("EDRL_BF16_KTAIL", 0);

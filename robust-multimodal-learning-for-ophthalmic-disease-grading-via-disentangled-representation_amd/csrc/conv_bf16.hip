@@ -1187,6 +1187,27 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
   return 0;
 }
 
+// Both gradients of an expanding 1x1 layer inside a fused-BatchNorm block in one pass over (g, yraw) (conv1x1_bwd_bf16.hip).
+int edrl_conv1x1_k64_bwd_ok_bf16(int N, int H, int W, int Ci, int Co) {
+  return (edrl_cfg().bf16_k64_bwd != 0 && conv1x1_k64_bwd_ok(N, H, W, Ci, Co)) ? 1 : 0;
+}
+long edrl_conv1x1_k64_bwd_chunks(int N, int H, int W) { return conv1x1_k64_bwd_chunks(N, H, W); }
+size_t edrl_conv1x1_k64_bwd_workspace_bytes(int N, int H, int W) { return conv1x1_k64_bwd_workspace_bytes(N, H, W); }
+int edrl_conv1x1_k64_bwd_bf16(const void* g_in, const void* yraw, const float* bcoef, const void* x2raw, const float* x2_fcoef,
+                              const void* wt, void* g2, float* ep_part, size_t ep_part_bytes, float* dw, float* workspace,
+                              size_t workspace_bytes, int N, int H, int W, int Ci, int Co, hipStream_t st) {
+  if (!g_in || !yraw || !bcoef || !x2raw || !x2_fcoef || !wt || !g2 || !ep_part || !dw || !workspace) return EDRL_EINVAL;
+  if (!conv1x1_k64_bwd_ok(N, H, W, Ci, Co)) return EDRL_EINVAL;
+  if (ep_part_bytes < (size_t)conv1x1_k64_bwd_chunks(N, H, W) * 2 * Ci * sizeof(float)) return EDRL_ENOSPC;
+  if (workspace_bytes < conv1x1_k64_bwd_workspace_bytes(N, H, W)) return EDRL_ENOSPC;
+  const int rc = launch_conv1x1_k64_bwd(g_in, yraw, bcoef, x2raw, x2_fcoef, wt, g2, ep_part, workspace, N, H, W, st);
+  if (rc) return rc;
+  const long n = (long)Co * Ci;
+  hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n, conv1x1_k64_bwd_splits(N, H, W), 0);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
 // The 7x7 / stride 2 / pad 3 stem of a 1-channel bf16 trunk as a bf16-MFMA streaming kernel (conv_c64_bf16.hip, ATR 2).
 int edrl_stem_conv_s2d_bf16(const float* xs, const void* w, void* y, float* stat_part, size_t stat_part_bytes, int N, int Hs, int Ws,
                             hipStream_t st) {

@@ -35,3 +35,12 @@ int launch_conv1x1_k64(const void* x, const float* in_fcoef, const void* w, void
 // space-to-depth image, operands rounded to bf16 in registers, bf16 MFMA, fp32 accumulate, bf16 output + BatchNorm chunk partials.
 bool stem_s2d_bf16_ok(int N, int Hs, int Ws);
 int launch_stem_s2d_bf16(const float* xs, const void* w, void* y, int N, int Hs, int Ws, float* stat_part, hipStream_t st);
+
+// Backward of the expanding 1x1 layers of the first residual stage (64 -> 256 channels) as one streaming kernel
+// (conv1x1_bwd_bf16.hip): weight gradient slabs [splits][256][64] + masked data gradient + BatchNorm-backward partial sums.
+bool conv1x1_k64_bwd_ok(int N, int H, int W, int Ci, int Co);
+long conv1x1_k64_bwd_chunks(int N, int H, int W);
+size_t conv1x1_k64_bwd_workspace_bytes(int N, int H, int W);
+int conv1x1_k64_bwd_splits(int N, int H, int W);
+int launch_conv1x1_k64_bwd(const void* g, const void* yraw, const float* bcoef, const void* x2, const float* x2coef, const void* wt,
+                           void* g2, float* ep_part, float* dw_slabs, int N, int H, int W, hipStream_t st);

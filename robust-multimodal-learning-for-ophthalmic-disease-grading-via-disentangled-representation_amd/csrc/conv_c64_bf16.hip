@@ -359,7 +359,19 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, KS == 2 ? 2 : 1) void conv1x1_
     // ---- the chunk's pixel fragments: 8 column tiles x KS K steps, 16 bytes per lane each
     c64_bf16x8 a[8][KS];
     if constexpr (ATR == 2) {
+      // Branch-free gather: every load goes through a buffer descriptor based at the chunk's first image; a window row / column
+      // outside the image (or a pixel past the end) is an out-of-range offset, which the hardware range check reads as zeros -- all
+      // 32 loads of the chunk are in flight together (the first version predicated each load: one exposed latency per load).
       const float* xs = reinterpret_cast<const float*>(src);
+      const int mu = __builtin_amdgcn_readfirstlane(m0);
+      const unsigned r0 = (unsigned)(((unsigned long long)(unsigned)mu * sg.mg_w) >> sg.sh_w);
+      const unsigned n0img = (unsigned)(((unsigned long long)r0 * sg.mg_h) >> sg.sh_h);
+      const long imgb = (long)sg.Hs * sg.Ws * 16;                     // bytes per image
+      long remb = (long)M * 16 - (long)n0img * imgb;
+      if (remb > 0x7fffffffL) remb = 0x7fffffffL;
+      const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + (long)n0img * sg.Hs * sg.Ws * 4), 0, (int)remb, 0x00020000);
+      constexpr unsigned OOBX = 0x80000000u;
+      f32x4 lo[8][KS], hi[8][KS];
 #pragma unroll
       for (int pt = 0; pt < 8; ++pt) {
         const int m = m0 + 16 * pt + pl;
@@ -367,21 +379,28 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, KS == 2 ? 2 : 1) void conv1x1_
         const int ow = m - (int)r * sg.Ws;
         const unsigned nimg = (unsigned)(((unsigned long long)r * sg.mg_h) >> sg.sh_h);
         const int oh = (int)r - (int)nimg * sg.Hs;
+        const int rowb = (int)(nimg - n0img) * sg.Hs;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int qp = 4 * ks + gq;                       // k chunk of 8: window row qp >> 1, columns 2 (qp & 1), 2 (qp & 1) + 1
           const int ih = oh - 2 + (qp >> 1), iw = ow - 2 + 2 * (qp & 1);
           const bool rowok = m < M && (unsigned)ih < (unsigned)sg.Hs;
-          const float* pp = xs + ((long)((int)nimg * sg.Hs + ih) * sg.Ws + iw) * 4;
-          f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-          if (rowok && (unsigned)iw < (unsigned)sg.Ws) lo = *reinterpret_cast<const f32x4*>(pp);
-          if (rowok && (unsigned)(iw + 1) < (unsigned)sg.Ws) hi = *reinterpret_cast<const f32x4*>(pp + 4);
-          c64_bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
-          a[pt][ks] = o;
+          const unsigned off = (unsigned)(((rowb + ih) * sg.Ws + iw) * 16);
+          const unsigned o0 = (rowok && (unsigned)iw < (unsigned)sg.Ws) ? off : OOBX;
+          const unsigned o1 = (rowok && (unsigned)(iw + 1) < (unsigned)sg.Ws) ? off + 16u : OOBX;
+          lo[pt][ks] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)o0, 0, 0));
+          hi[pt][ks] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)o1, 0, 0));
         }
       }
+#pragma unroll
+      for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          c64_bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[pt][ks][e]; o[4 + e] = (__bf16)hi[pt][ks][e]; }
+          a[pt][ks] = o;
+        }
     } else {
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {

@@ -12,6 +12,7 @@ struct EdrlConfig {
   int bf16_wgrad_v3;     // EDRL_BF16_WGRAD_V3    0 | 1 | 2: 256x256 LDS-DMA weight-gradient core
   int bf16_c64;          // EDRL_BF16_C64         0 | 1 | 2: weight-stationary 64 -> 64 3x3 kernel
   int bf16_k64;          // EDRL_BF16_K64         0 | 1 | 2: streaming expanding-1x1 kernel
+  int bf16_k64_bwd;      // EDRL_BF16_K64_BWD     0: the expanding 1x1 layers' backward as two kernels (weight gradient, data gradient)
   int stem_pool_v8;      // EDRL_STEM_POOL_V8     0: 4-channel lanes in the fused stem pool kernels
   int bf16_epi_vw4;      // EDRL_BF16_EPI_VW4     1: 4-channel epilogue lanes in the 128-row kernel
   int bf16_ktail;        // EDRL_BF16_KTAIL       1: keep the load round past the last K tile

@@ -195,6 +195,8 @@ class _K32:
     fuse_max_planes = 1 << 30        # every residual stage takes the fused-BatchNorm path
     mid_sep = False                  # (bf16 only) the 3x3 layer of a fused bottleneck block on the plain kernels
     wide_sep = False                 # (bf16 only) see _KBF16
+    conv3_bwd_ok = staticmethod(lambda *a: False)       # (bf16 only) one-pass backward of the expanding 1x1 layers
+    conv3_bwd = None
     grad_in = staticmethod(lambda dout: dout.contiguous())
     feat_out = staticmethod(lambda cur: cur)
 
@@ -312,6 +314,8 @@ class _KBF16:
     # mask) and the separate dres tensor of the block's last BatchNorm; the block output comes from bn_apply_res as in a fused block,
     # so the gradient hand-over between blocks stays ("masked", g, partials).  EDRL_BF16_WIDE_SEP=0: the separate passes of round 3.
     wide_sep = os.environ.get("EDRL_BF16_WIDE_SEP", "1") != "0"
+    conv3_bwd_ok = staticmethod(lambda *a: ops.conv1x1_k64_bwd_ok_bf16(*a))
+    conv3_bwd = staticmethod(lambda *a: ops.conv1x1_k64_bwd_bf16(*a))
     grad_in = staticmethod(lambda dout: ops.to_bf16(dout.contiguous()))
     feat_out = staticmethod(lambda cur: ops.to_f32(cur))
 
@@ -751,10 +755,14 @@ class _TrunkFn(torch.autograd.Function):
                     continue
                 if bott:
                     c2, f2 = rec["c2"], rec["f2"]
-                    fwgrad(last, gl, cl, bl, c2, f2, 1, 0)
-                    fcap(last, last_bn, gl, cl, bl, dres=gl.clone() if cap is not None else None)
-                    g2, part, chunks = fdgrad(last, gl, cl, bl, c2.shape, 1, 0, ep=(c2, None, f2, True),
-                                              ep_keep=recompute_keep(c2, f2))
+                    if cap is None and K.conv3_bwd_ok(c2.shape[0], c2.shape[1], c2.shape[2], c2.shape[3], cl.shape[3]):
+                        # expanding 1x1 layer of the first stage: both gradients from one pass over (gl, cl)
+                        grads[last + ".weight"], g2, part, chunks = K.conv3_bwd(gl, cl, bl, c2, f2, wt_of(last))
+                    else:
+                        fwgrad(last, gl, cl, bl, c2, f2, 1, 0)
+                        fcap(last, last_bn, gl, cl, bl, dres=gl.clone() if cap is not None else None)
+                        g2, part, chunks = fdgrad(last, gl, cl, bl, c2.shape, 1, 0, ep=(c2, None, f2, True),
+                                                  ep_keep=recompute_keep(c2, f2))
                     b2 = fin_bwd(pre + ".bn2", part, chunks, 2, c2, f2)
                     planes1 = 2
                     if rec.get("mid_sep"):

@@ -1159,6 +1159,30 @@ def conv2d_dgrad_bn_bf16(g, yraw, bcoef, wt, x_shape, stride=1, pad=0, out=None,
     return out if ep is None else (out, part, chunks)
 
 
+def conv1x1_k64_bwd_ok_bf16(N, H, W, Ci, Co):
+    return bool(L.query("edrl_conv1x1_k64_bwd_ok_bf16", N, H, W, Ci, Co))
+
+
+def conv1x1_k64_bwd_bf16(g, yraw, bcoef, x2raw, x2_fcoef, wt):
+    """Both gradients of an expanding 1x1 layer (64 -> 256) inside a fused-BatchNorm block from one pass over (g, yraw)
+    (csrc/conv1x1_bwd_bf16.hip).  -> (dw fp32 [Co,1,1,Ci], g2 bf16 [N,H,W,Ci] masked with bn(x2raw)'s ReLU decision,
+    part [chunks][2][Ci] = (sum g2, sum g2*(x2raw - mean)), chunks)."""
+    N, H, W, Co = g.shape
+    Ci = x2raw.shape[-1]
+    dev = g.device
+    g2 = torch.empty((N, H, W, Ci), device=dev, dtype=torch.bfloat16)
+    chunks = L.query("edrl_conv1x1_k64_bwd_chunks", N, H, W)
+    part = torch.empty((chunks, 2, Ci), device=dev, dtype=torch.float32)
+    nbytes = L.query("edrl_conv1x1_k64_bwd_workspace_bytes", N, H, W)
+    ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+    dw = torch.empty((Co, 1, 1, Ci), device=dev, dtype=torch.float32)
+    M = N * H * W
+    _launch_timed("conv_bwd_k64_bf16", 4.0 * M * Co * Ci, "edrl_conv1x1_k64_bwd_bf16", P(g), P(yraw), P(bcoef), P(x2raw), P(x2_fcoef),
+                  P(wt), P(g2), P(part), part.numel() * 4, P(dw), P(ws), nbytes, N, H, W, Ci, Co, kernels=2,
+                  nbytes=2.0 * (2 * g.numel() + x2raw.numel() + g2.numel() + wt.numel()) + 4.0 * dw.numel())
+    return dw, g2, part, chunks
+
+
 def conv2d_wgrad_bn_bf16(g, yraw, bcoef, x, x_fcoef, w_shape, stride=1, pad=0):
     N, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = g.shape

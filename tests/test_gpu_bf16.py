@@ -817,3 +817,57 @@ def test_stem_bf16_mma_kernel_vs_fp64_and_fp32_mfma_stem(edrl, dev, N, H, W):
         d = blk - K
         assert float((pv[c, 0].double() - d.sum(0)).abs().max()) <= 1e-3 * max(float(d.abs().sum(0).max()), 1e-6), f"chunk {c} S1"
         assert float((pv[c, 1].double() - (d * d).sum(0)).abs().max()) <= 1e-3 * max(float((d * d).sum(0).max()), 1e-6), f"chunk {c} S2"
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 14, 14), (2, 9, 7), (1, 8, 8), (5, 28, 28), (1, 3, 5)])
+def test_conv1x1_k64_bwd_one_pass_kernel_vs_fp64_and_two_kernel_path(edrl, dev, N, H, W, switches):
+    """Backward of the expanding 1x1 layers of the first residual stage (64 -> 256) in ONE pass over (g, yraw)
+    (csrc/conv1x1_bwd_bf16.hip): pixel counts off the 128-pixel tile, fewer tiles than workgroups, one tile only.  Against fp64 on
+    the SAME storage-rounded operands (d_raw and the activation rounded to bf16 as the kernels hold them): weight gradient 2e-5 of
+    its max (fp32 accumulation of bf16 products, ordered split reduction), masked data gradient one bf16 ulp, the summed partials
+    (sum g2, sum g2*(x2 - mean)) 1e-3 of sum |.|; and against the two-kernel path of rounds 2-3 (fused weight gradient + fused data
+    gradient with epilogue), which forms the same operands with the same arithmetic; run twice: bit-identical (deterministic)."""
+    ops = edrl.ops
+    Ci, Co = 64, 256
+    g = torch.Generator().manual_seed(N * 131 + H)
+    q = lambda t: t.bfloat16()
+    gy = q(torch.randn(N, H, W, Co, generator=g))
+    yraw = q(torch.randn(N, H, W, Co, generator=g) + 0.3)
+    bc = torch.empty(4, Co); bc[0] = 0.5 + torch.rand(Co, generator=g); bc[1] = 0.05 * torch.randn(Co, generator=g)
+    bc[2] = 0.05 * torch.randn(Co, generator=g); bc[3].zero_()
+    x2 = q(torch.randn(N, H, W, Ci, generator=g) + 0.2)
+    fin = torch.empty(5, Ci); fin[0] = 0.2 + 0.1 * torch.randn(Ci, generator=g); fin[1].fill_(1.0)
+    fin[2] = 0.5 + torch.rand(Ci, generator=g); fin[3] = 0.2 * torch.randn(Ci, generator=g); fin[4] = fin[3] - fin[0] * fin[2]
+    w = q(torch.randn(Co, 1, 1, Ci, generator=g) * 0.1)
+    # fp64 reference on the storage-rounded operands
+    # (the kernels' fused multiply-adds, one rounding each, emulated through fp64 so that no bf16 rounding boundary is crossed)
+    inner = (bc[0].double() * gy.double() + bc[2].double()).float()
+    d3 = q((bc[1].double() * yraw.double() + inner.double()).float()).double().reshape(-1, Co)
+    pre = (x2.double() * fin[2].double() + fin[4].double()).float()
+    a2 = q(torch.relu(pre)).double().reshape(-1, Ci)
+    dw_ref = d3.t() @ a2
+    keep = (pre > 0).reshape(-1, Ci)
+    care = (pre.abs() > 1e-6 * pre.abs().max()).reshape(-1, Ci).double()
+    g2_ref = (d3 @ w.double().reshape(Co, Ci)) * keep.double()
+    dev_ = lambda t: t.to(dev)
+    wt = ops.permute_weight_bf16(w.float().to(dev))
+    assert ops.conv1x1_k64_bwd_ok_bf16(N, H, W, Ci, Co)
+    dw, g2, part, chunks = ops.conv1x1_k64_bwd_bf16(dev_(gy), dev_(yraw), dev_(bc), dev_(x2), dev_(fin), wt)
+    dw_b, g2_b, part_b, _ = ops.conv1x1_k64_bwd_bf16(dev_(gy), dev_(yraw), dev_(bc), dev_(x2), dev_(fin), wt)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw_b) and torch.equal(g2, g2_b) and torch.equal(part, part_b), "deterministic"
+    check(f"one-pass 1x1 bwd dW {N}x{H}x{W}", dw.cpu().reshape(Co, Ci), dw_ref, 2e-5)
+    err = ((g2.double().cpu().reshape(-1, Ci) - g2_ref) * care).abs().max() / g2_ref.abs().max()
+    print(f"[parity] one-pass 1x1 bwd g2 {N}x{H}x{W}: max-rel-err {err:.3e} (tol {BF16_TOL:.1e})")
+    assert err <= BF16_TOL
+    xs = x2.double().reshape(-1, Ci) - fin[0].double()
+    tot = part.double().sum(0).cpu()
+    gm = g2_ref * care
+    assert float((tot[0] - gm.sum(0)).abs().max()) <= 1e-3 * float(g2_ref.abs().sum(0).max()), "sum g2"
+    assert float((tot[1] - (gm * xs).sum(0)).abs().max()) <= 1e-3 * float((g2_ref.abs() * xs.abs()).sum(0).max()), "sum g2*(x2-mean)"
+    # the two-kernel path of rounds 2-3 on the same operands
+    dw2 = ops.conv2d_wgrad_bn_bf16(dev_(gy), dev_(yraw), dev_(bc), dev_(x2), dev_(fin), (Co, 1, 1, Ci), 1, 0)
+    g22, part2, _ = ops.conv2d_dgrad_bn_bf16(dev_(gy), dev_(yraw), dev_(bc), wt, (N, H, W, Ci), 1, 0, ep=(dev_(x2), None, dev_(fin), True))
+    check("one-pass vs two-kernel dW", dw.cpu(), dw2.cpu(), 2e-5)
+    e2 = ((g2.double() - g22.double()).cpu().reshape(-1, Ci) * care).abs().max() / g2_ref.abs().max()
+    assert e2 <= BF16_TOL, f"one-pass vs two-kernel g2: {e2:.3e}"
