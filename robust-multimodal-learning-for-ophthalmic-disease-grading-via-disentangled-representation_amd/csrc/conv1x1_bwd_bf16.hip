@@ -12,19 +12,21 @@
 // are tiny next to the bytes (0.2 us of MFMA per 128 pixels against 7.6 us of HBM time per CU), so the only lever is to read the
 // pair once: 15.6 GB -> 8.2 GB per call.
 //
-// Skeleton (weight-stationary, persistent): 256 workgroups x 512 threads, one per CU; the permuted weights Wt [64][256] sit in LDS
-// in MFMA-fragment order for the whole launch.  Per 128-pixel tile:
-//   * every thread has the NEXT tile's 18 16-byte pieces (8 of g, 8 of y, 2 of x2) in flight in registers while the current tile
-//     is multiplied; when a piece is consumed its register is re-issued for the tile after (the HBM queue never drains);
+// Skeleton (weight-stationary, persistent): 512 workgroups x 256 threads, TWO per CU (72 KiB of LDS and the whole register file of
+// one wave per SIMD each: while one multiplies, the other converts and stages -- the first version, one 512-thread workgroup per CU
+// on 128-pixel tiles, ran its phases in lockstep at 3.7 TB/s); the permuted weights Wt [64][256] sit in LDS in MFMA-fragment order
+// for the whole launch.  Per 64-pixel tile:
+//   * every thread requests the tile's 18 16-byte pieces (8 of g, 8 of y, 2 of x2) at once; while they fly the other workgroup
+//     of the CU multiplies its tile (two workgroups x 72 KiB in flight keep the HBM queue full);
 //   * d3 is formed once per element (fp32 fma, one rounding -- the arithmetic of conv_bf16.hip's ATR 2 operand) and written to an
-//     LDS image [128 px][256 co] whose 16-byte chunks are XOR-swizzled with S(row) = ((row&3)<<2)|((row>>2)&3): conflict-free BOTH
+//     LDS image [64 px][256 co] whose 16-byte chunks are XOR-swizzled with S(row) = ((row&3)<<2)|((row>>2)&3): conflict-free BOTH
 //     for the row reads of the data gradient (ds_read_b128, 16 rows at one chunk per lane group) and for the transposing reads of the
-//     weight gradient (ds_read_b64_tr_b16, 4 rows x 4 chunks per 32-lane half); x2 goes to LDS raw, [128][64], swizzled likewise;
+//     weight gradient (ds_read_b64_tr_b16, 4 rows x 4 chunks per 32-lane half); x2 goes to LDS raw, [64][64], swizzled likewise;
 //   * data gradient: wave w owns pixels 32 (w>>1) .. +31 x channels 32 (w&1) .. +31, K = 256: 16 v_mfma_f32_32x32x16_bf16 with the
 //     weight fragment as first operand -> a lane holds 4 x 4 consecutive channels of ONE pixel; epilogue in registers: ReLU decision
 //     of bn2 recomputed from the raw x2 tile (same fma as the forward), masked gradient stored (8-byte pieces), partial sums kept
-//     per lane for the whole launch and reduced once at the end -> ep_part [4 * workgroup + pixel block][2][64];
-//   * weight gradient: wave w owns output channels 32 w .. +31 x all 64 input channels, K = 128 pixels: 16 MFMAs on transposed
+//     per lane for the whole launch and reduced once at the end -> ep_part [2 * workgroup + pixel block][2][64];
+//   * weight gradient: wave w owns output channels 64 w .. +63 x all 64 input channels, K = 64 pixels: 16 MFMAs on transposed
 //     fragments, a2 formed on the fragment (a lane owns ONE input channel of its 8 pixels); fp32 accumulators live in registers
 //     across all tiles of the workgroup -> one [256][64] slab per workgroup, summed in fixed order by splitk_reduce_h_kernel.
 // Deterministic: static tile -> workgroup assignment, ordered reductions, no atomics.
@@ -39,10 +41,11 @@ typedef short b1_s16x4 __attribute__((ext_vector_type(4)));
 
 #define B1_CI 64
 #define B1_CO 256
-#define B1_P 128                                   // pixels per tile
+#define B1_P 64                                    // pixels per tile
+#define B1_NT 256                                  // threads per workgroup (4 waves; two workgroups per CU)
 #define B1_W_BYTES (16 * 2 * 64 * 16)              // 32 KiB: Wt fragments [k step][channel tile][lane]
-#define B1_D_BYTES (B1_P * B1_CO * 2)              // 64 KiB: d3 image
-#define B1_X_BYTES (B1_P * B1_CI * 2)              // 16 KiB: raw x2 image
+#define B1_D_BYTES (B1_P * B1_CO * 2)              // 32 KiB: d3 image
+#define B1_X_BYTES (B1_P * B1_CI * 2)              // 8 KiB: raw x2 image
 #define B1_T_BYTES ((3 * B1_CO + 3 * B1_CI) * 4)   // coefficient tables: A, nK2, C2 [256]; scale, shift2, mean [64]
 #define B1_LDS (B1_W_BYTES + B1_D_BYTES + B1_X_BYTES + B1_T_BYTES)
 
@@ -68,7 +71,7 @@ __device__ __forceinline__ b1_bf16x8 b1_tr_frag(const unsigned char* img, int pi
   return u.v;
 }
 
-__global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
+__global__ __launch_bounds__(B1_NT, 2) void conv1x1_k64_bwd_bf16_kernel(
     const __bf16* __restrict__ gin, const __bf16* __restrict__ yraw, const float* __restrict__ bcoef,
     const __bf16* __restrict__ x2, const float* __restrict__ x2coef, const __bf16* __restrict__ wt, __bf16* __restrict__ g2,
     float* __restrict__ ep_part, float* __restrict__ dw_slabs, int M, int ntiles) {
@@ -82,12 +85,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
 
   // ---- weights -> LDS in fragment order: fragment (k step ks, channel tile ct), lane l = (row ci = 32 ct + (l & 31),
   //      k = output channels 16 ks + 8 (l >> 5) .. +7) of Wt [64][256]
-  for (int idx = tid; idx < 16 * 2 * 64; idx += 512) {
+  for (int idx = tid; idx < 16 * 2 * 64; idx += B1_NT) {
     const int l = idx & 63, ct = (idx >> 6) & 1, ks = idx >> 7;
     *reinterpret_cast<b1_bf16x8*>(wl + idx * 16) =
         *reinterpret_cast<const b1_bf16x8*>(wt + (long)(32 * ct + (l & 31)) * B1_CO + 16 * ks + 8 * (l >> 5));
   }
-  for (int i = tid; i < 3 * B1_CO; i += 512) tab[i] = bcoef[i];                                        // rows 0..2 of bcoef [4][256]
+  for (int i = tid; i < 3 * B1_CO; i += B1_NT) tab[i] = bcoef[i];                                        // rows 0..2 of bcoef [4][256]
   if (tid < B1_CI) {
     tab[3 * B1_CO + tid] = x2coef[2 * B1_CI + tid];                                                    // scale
     tab[3 * B1_CO + B1_CI + tid] = x2coef[4 * B1_CI + tid];                                            // shift2
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
   const float* tA = tab, *tK = tab + B1_CO, *tC = tab + 2 * B1_CO;
   const float* tsc = tab + 3 * B1_CO, *tsh = tsc + B1_CI, *tmu = tsh + B1_CI;
 
-  // ---- staging coordinates: d3 pieces (row = (tid >> 5) + 16 i, chunk = tid & 31), x2 pieces (id = tid + 512 i: row id >> 3, chunk id & 7)
+  // ---- staging coordinates: d3 pieces (row = (tid >> 5) + 8 i, chunk = tid & 31), x2 pieces (id = tid + 256 i: row id >> 3, chunk id & 7)
   const int drow = tid >> 5, dchunk = tid & 31;
   b1_bf16x8 G[8], Y[8], X[2];
   auto issue = [&](int tile, int i) {             // piece i of g / y (i < 8) of `tile`: rows past M read as zeros (range check)
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
     long rows = (long)M - m0; if (rows > B1_P) rows = B1_P; if (rows < 0) rows = 0;
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gin + m0 * B1_CO), 0, (int)(rows * B1_CO * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yraw + m0 * B1_CO), 0, (int)(rows * B1_CO * 2), 0x00020000);
-    const int off = ((drow + 16 * i) * B1_CO + dchunk * 8) * 2;
+    const int off = ((drow + 8 * i) * B1_CO + dchunk * 8) * 2;
     G[i] = __builtin_bit_cast(b1_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
     Y[i] = __builtin_bit_cast(b1_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
   };
@@ -113,16 +116,18 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
     const long m0 = (long)tile * B1_P;
     long rows = (long)M - m0; if (rows > B1_P) rows = B1_P; if (rows < 0) rows = 0;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x2 + m0 * B1_CI), 0, (int)(rows * B1_CI * 2), 0x00020000);
-    const int id = tid + 512 * i;
+    const int id = tid + B1_NT * i;
     X[i] = __builtin_bit_cast(b1_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, ((id >> 3) * B1_CI + (id & 7) * 8) * 2, 0, 0));
   };
 
   // ---- accumulators that live for the whole launch
-  f32x16 accw[2];                                 // weight gradient: rows 32 wave .. +31, columns 32 ct .. +31
+  f32x16 accw[2][2];                              // weight gradient: rows 32 (2 wave + b) .. +31, columns 32 ct .. +31
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accw[c][r] = 0.f;
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw[b][c][r] = 0.f;
   const int pb = wave >> 1, dct = wave & 1;       // data gradient: pixel block, channel tile of this wave
   const int lh = lane >> 5, li = lane & 31;
   f32x4 es0[4], es1[4];                           // (sum g2, sum g2*(x2 - mean)) of this lane's 4 x 4 channels
@@ -130,16 +135,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
   for (int j = 0; j < 4; ++j) es0[j] = es1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float wsc[2] = {tsc[li], tsc[32 + li]}, wsh[2] = {tsh[li], tsh[32 + li]};     // weight gradient: this lane's input channel per tile
 
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long m0 = (long)tile * B1_P;
+    // the tile's 18 pieces per thread: all in flight together; the OTHER workgroup of the CU multiplies meanwhile (no register
+    // prefetch across tiles: with 64 accumulator registers of the weight gradient it would not fit the 256-register budget)
 #pragma unroll
     for (int i = 0; i < 8; ++i) issue(tile, i);
 #pragma unroll
     for (int i = 0; i < 2; ++i) issue_x(tile, i);
-  }
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long m0 = (long)tile * B1_P;
-    const int nxt = tile + gridDim.x;             // (past the end: zero-size descriptors, the loads return zeros)
     // ---- consume the tile's pieces: d3 -> LDS, x2 raw -> LDS; each register is re-issued for the next tile as soon as it is read
     f32x4 cA[2], cK[2], cC[2];                    // A, nK2, C2 of this thread's 8 output channels (from the LDS table: no registers held
 #pragma unroll                                   //  across the multiply phase)
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int row = drow + 16 * i;
+      const int row = drow + 8 * i;
       const bool ok = m0 + row < M;
       b1_bf16x8 d;
 #pragma unroll
@@ -158,17 +161,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
         const float v = __builtin_fmaf(cK[e >> 2][e & 3], (float)Y[i][e], __builtin_fmaf(cA[e >> 2][e & 3], (float)G[i][e], cC[e >> 2][e & 3]));
         d[e] = ok ? (__bf16)v : (__bf16)0.f;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      issue(nxt, i);
+
       const int slot = (dchunk & 16) | ((dchunk & 15) ^ b1_sd(row));
       *reinterpret_cast<b1_bf16x8*>(dimg + row * (B1_CO * 2) + slot * 16) = d;
-      __builtin_amdgcn_sched_barrier(0);          // piece by piece: consume, re-issue (no second register set for the old values)
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const b1_bf16x8 xv = X[i];
-      const int id = tid + 512 * i, row = id >> 3, chunk = id & 7;
-      issue_x(nxt, i);
+      const int id = tid + B1_NT * i, row = id >> 3, chunk = id & 7;
       *reinterpret_cast<b1_bf16x8*>(ximg + row * (B1_CI * 2) + ((chunk ^ b1_sx(row)) * 16)) = xv;
     }
     __syncthreads();
@@ -215,19 +215,23 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
         }
       }
     }
-    // ---- weight gradient: D[co 32][ci 32] += d3^T a2 over the tile's 128 pixels (8 k steps of 16)
+    // ---- weight gradient: D[co 32][ci 32] += d3^T a2 over the tile's 64 pixels (4 k steps of 16); this wave: co blocks 2 w, 2 w + 1
 #pragma unroll 2
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       const int pix0 = 16 * ks + 8 * lh;
       const int cg = 16 * ((lane >> 4) & 1);
-      const b1_bf16x8 af = b1_tr_frag<B1_CO * 2, true>(dimg, pix0, 32 * wave + cg, lane);
+      b1_bf16x8 bf[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const b1_bf16x8 xr = b1_tr_frag<B1_CI * 2, false>(ximg, pix0, 32 * c + cg, lane);
-        b1_bf16x8 bf;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bf[e] = (__bf16)fmaxf(__builtin_fmaf((float)xr[e], wsc[c], wsh[c]), 0.f);
-        accw[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accw[c], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) bf[c][e] = (__bf16)fmaxf(__builtin_fmaf((float)xr[e], wsc[c], wsh[c]), 0.f);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const b1_bf16x8 af = b1_tr_frag<B1_CO * 2, true>(dimg, pix0, 32 * (2 * wave + b) + cg, lane);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) accw[b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[c], accw[b][c], 0, 0, 0);
       }
     }
     __syncthreads();                                // every read of the tile images is done: the next tile may overwrite them
@@ -236,10 +240,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
   // ---- weight-gradient slab of this workgroup: rows (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32, column 32 c + li
   float* slab = dw_slabs + (long)blockIdx.x * B1_CO * B1_CI;
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      slab[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh) * B1_CI + 32 * c + li] = accw[c][r];
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[(32 * (2 * wave + b) + (r & 3) + 8 * (r >> 2) + 4 * lh) * B1_CI + 32 * c + li] = accw[b][c][r];
   // ---- BatchNorm-backward partial sums: reduce over the 32 pixel lanes of each half, one chunk per (workgroup, pixel block)
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
       }
     }
   if (li == 0) {
-    float* pp = ep_part + ((long)blockIdx.x * 4 + pb) * 2 * B1_CI;
+    float* pp = ep_part + ((long)blockIdx.x * 2 + pb) * 2 * B1_CI;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       *reinterpret_cast<f32x4*>(pp + 32 * dct + 8 * j + 4 * lh) = es0[j];
@@ -264,13 +270,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_k64_bwd_bf16_kernel(
 // ---------------------------------------------------------------------------------------------------------------- host side
 static int b1_grid(long M) {
   const long nt = (M + B1_P - 1) / B1_P;
-  return (int)(nt < 256 ? nt : 256);
+  return (int)(nt < 512 ? nt : 512);
 }
 bool conv1x1_k64_bwd_ok(int N, int H, int W, int Ci, int Co) {
   const long M = (long)N * H * W;
   return Ci == B1_CI && Co == B1_CO && N > 0 && M > 0 && M < 0x7fffff00L;
 }
-long conv1x1_k64_bwd_chunks(int N, int H, int W) { return 4L * b1_grid((long)N * H * W); }
+long conv1x1_k64_bwd_chunks(int N, int H, int W) { return 2L * b1_grid((long)N * H * W); }
 size_t conv1x1_k64_bwd_workspace_bytes(int N, int H, int W) { return (size_t)b1_grid((long)N * H * W) * B1_CO * B1_CI * sizeof(float); }
 int conv1x1_k64_bwd_splits(int N, int H, int W) { return b1_grid((long)N * H * W); }
 
@@ -284,7 +290,7 @@ int launch_conv1x1_k64_bwd(const void* g, const void* yraw, const float* bcoef, 
   auto kern = conv1x1_k64_bwd_bf16_kernel;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS); attr = true; }
-  hipLaunchKernelGGL(kern, dim3(b1_grid(M)), dim3(512), B1_LDS, st, (const __bf16*)g, (const __bf16*)yraw, bcoef, (const __bf16*)x2,
+  hipLaunchKernelGGL(kern, dim3(b1_grid(M)), dim3(B1_NT), B1_LDS, st, (const __bf16*)g, (const __bf16*)yraw, bcoef, (const __bf16*)x2,
                      x2coef, (const __bf16*)wt, (__bf16*)g2, ep_part, dw_slabs, (int)M, ntiles);
   EDRL_LAUNCH_CHECK();
   return 0;
