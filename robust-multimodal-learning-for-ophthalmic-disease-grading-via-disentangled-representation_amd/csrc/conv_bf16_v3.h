@@ -44,3 +44,8 @@ size_t conv1x1_k64_bwd_workspace_bytes(int N, int H, int W);
 int conv1x1_k64_bwd_splits(int N, int H, int W);
 int launch_conv1x1_k64_bwd(const void* g, const void* yraw, const float* bcoef, const void* x2, const float* x2coef, const void* wt,
                            void* g2, float* ep_part, float* dw_slabs, int N, int H, int W, hipStream_t st);
+
+// Persistent form of the core (conv_bf16_v3p.hip: next tile's first units issued before the epilogue, register epilogue): plain
+// forward / data gradient (GF_STATS, GF_ACCUM, strided classes); same geometry conditions as gather_bf16_v3_ok.
+bool gather_bf16_v3p_ok(const GatherGeom& g);
+int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st);

@@ -512,6 +512,14 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
   static bool attr_set[3] = {false, false, false};
   GatherFuse F;
   memset(&F, 0, sizeof(F));
+#ifdef EDRL_DIAG
+  const bool diag = edrl_cfg().diag_v3 != 0;
+#else
+  const bool diag = false;
+#endif
+  if (!(fuse && fuse->ep_x) && !diag && edrl_cfg().v3_stagger != 1 && gather_bf16_v3p_ok(g))
+    return launch_gather_bf16_v3p(src, wm, dst, g, dgrad, st);      // plain forward / data gradient: the persistent form
+
   if (fuse && fuse->ep_x) {      // data gradient with the BatchNorm-backward epilogue (mask + partial sums)
     if (!dgrad || !gather_bf16_v3_epi_ok(g, *fuse)) return EDRL_EINVAL;
     auto ke = conv_gather_bf16_v3_kernel<true, 0, false, 2, 1>;

@@ -1,0 +1,354 @@
+// Persistent form of the 256x256 LDS-DMA bf16 implicit-GEMM core (conv_bf16_v3.hip): same tile, ring and K loop, but a workgroup
+// walks a list of tiles and the work that used to run with an idle matrix pipe between two tiles is taken off the critical path:
+//   * the next tile's row decode and its first three ring units (12 LDS-DMA pieces per wave) are issued BEFORE the current tile's
+//     epilogue, so the cold first loads (2-3 k cycles) fly behind the stores;
+//   * the epilogue leaves from REGISTERS: v_permlane16_swap trades two accumulator tiles between lane rows so that a lane holds 8
+//     consecutive channels (16-byte stores, 64 contiguous bytes per pixel and instruction) -- no LDS image, so the ring is free for
+//     the next tile as soon as the last fragment has been read; BatchNorm chunk partials come straight from the accumulators as before;
+//   * the row decode uses the host-made magic divisors of GatherGeom (no 64-bit divisions).
+// In-kernel stamps of round 3 (profiles/r03_v3_dma_ablation.txt): prologue 9.5 k + epilogue 7.1 k cycles of 119 k per `l3 3x3 256`
+// tile with nothing overlapping them (one workgroup per CU).  Tiles are dealt so that the tiles of one XCD stay a contiguous range
+// (operand panels shared in that XCD's L2), 32 workgroups per XCD striding through it.
+// Plain forward / data gradient only (GF_STATS, GF_ACCUM, strided parity classes); the BatchNorm-backward epilogue (EPI 1) stays on
+// the one-tile-per-workgroup kernel, whose cross-wave reduction needs the LDS anyway.  EDRL_BF16_V3_PERSIST=0: off.
+#include "edrl_common.h"
+#include "edrl_config.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "conv_bf16_v3.h"
+#include "lds_dma.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define V3_BM 256
+#define V3_BN 256
+#define V3_BK 32
+#define V3_ABYTES (V3_BM * V3_BK * 2)      // 16 KiB
+#define V3_BBYTES (V3_BN * V3_BK * 2)      // 16 KiB
+#define V3_UNIT (V3_ABYTES + V3_BBYTES)    // 32 KiB
+#define V3_LDS (4 * V3_UNIT)               // 128 KiB ring
+
+__device__ __forceinline__ int v3p_swz(int r) {
+  const int q = (r >> 2) & 3;
+  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
+}
+
+template <bool DGRAD>
+__global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf16* __restrict__ src, const __bf16* __restrict__ wm,
+                                                                      __bf16* __restrict__ dst, GatherGeom g, int tiles_n, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TM = 8, TN = 4;                 // wave tile 128 pixels x 64 channels of 16x16 MFMA tiles
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+  // ---- tile list of this workgroup: XCD x owns the contiguous tile range [tbase, tbase + tcount), its workgroups stride through it
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, wstride = gridDim.x >> 3;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tbase = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tcount = tq + (xcd < tr ? 1 : 0);
+  int tk = wslot;
+  if (tk >= tcount) return;
+
+  const int srow = tid >> 2;                                   // 0..127
+  const int kc8 = (((tid & 3) ^ v3p_swz(srow)) * 8);
+  const int ohw = g.OHs * g.OWs;
+  const bool lin = g.KH == 1 && g.KW == 1 && g.pad == 0 && g.stride == 1 && g.step == 1 && g.SH == g.OHs && g.SW == g.OWs;
+  constexpr unsigned OOB = 0x80000000u;
+  const v3_i32x4 rs_b = v3_make_srd(wm, (unsigned)((long)g.NC * g.Kfull * 2));
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(lds_ptr_t)smem) + (unsigned)wave * 1024u;
+  const int wj = 128 * g.Kfull * 2;
+
+  // ---- state of the tile being LOADED
+  long m0 = 0;
+  int n0 = 0;
+  int pb[2], hw[2];
+  v3_i32x4 rs_a;
+  unsigned wrow0 = 0;
+  unsigned aoff[2], boff;
+  int ta = 0, tb = 0, cb = 0;
+  auto retap = [&]() {
+    const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
+    const int tapoff = (kh * g.KW + kw) * g.SC;
+    const bool kvalid = ta < g.KHs && g.KWs > 0;      // false past the last tap: the tail pieces of the pipeline read as zeros
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rh = (int)((unsigned)hw[j] >> 16) - 16384, rw = (hw[j] & 0xffff) - 16384;
+      int sh, sw;
+      bool ok = kvalid && pb[j] >= 0;
+      if (DGRAD) {
+        const int th = rh - kh, tw = rw - kw;
+        ok = ok && th >= 0 && tw >= 0;
+        sh = th >> g.sshift; sw = tw >> g.sshift;
+      } else { sh = rh + kh; sw = rw + kw; }
+      ok = ok && (unsigned)sh < (unsigned)g.SH && (unsigned)sw < (unsigned)g.SW;
+      const unsigned pix = (unsigned)(pb[j] + sh * g.SW + sw);
+      aoff[j] = ok ? pix * (unsigned)(g.ld_src * 2) + (unsigned)(cb + kc8) * 2u : OOB;
+    }
+    boff = kvalid ? wrow0 + (unsigned)(tapoff + cb + kc8) * 2u : OOB;
+  };
+  auto advance = [&]() {
+    cb += V3_BK;
+    if (cb >= g.SC) { cb = 0; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
+    else {
+      aoff[0] += V3_BK * 2; aoff[1] += V3_BK * 2;       // (an OOB offset stays out of range: 2^31 + a few KiB)
+      boff += V3_BK * 2;
+    }
+  };
+  // decode of tile `lid` (logical id = tile_m * tiles_n + tile_n): rows srow + 128 j of both operand units, descriptors, first tap
+  auto setup = [&](int lid) {
+    const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+    m0 = (long)tile_m * V3_BM;
+    n0 = tile_n * V3_BN;
+    const int n_first = (int)(((unsigned long long)(unsigned)m0 * g.mg_ohw) >> g.sh_ohw);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long m = m0 + srow + 128 * j;
+      if (lin) {
+        pb[j] = m < g.M ? (int)(m - (long)n_first * ohw) : -1;
+        hw[j] = (16384 << 16) | 16384;
+      } else if (m < g.M) {
+        const int n = (int)(((unsigned long long)(unsigned)m * g.mg_ohw) >> g.sh_ohw);
+        const int rem = (int)m - n * ohw;
+        const int ii = (int)(((unsigned long long)(unsigned)rem * g.mg_ow) >> g.sh_ow), jj = rem - ii * g.OWs;
+        const int oh = g.h0 + ii * g.step, ow = g.w0 + jj * g.step;
+        int rh, rw;
+        if (DGRAD) { rh = oh + g.pad; rw = ow + g.pad; }
+        else       { rh = oh * g.stride - g.pad; rw = ow * g.stride - g.pad; }
+        pb[j] = (n - n_first) * g.SH * g.SW;
+        hw[j] = ((rh + 16384) << 16) | (rw + 16384);
+      } else { pb[j] = -1; hw[j] = 0; }
+    }
+    long mlast = m0 + V3_BM; if (mlast > g.M) mlast = g.M;
+    const int n_last = (int)(((unsigned long long)(unsigned)(mlast - 1) * g.mg_ohw) >> g.sh_ohw);
+    const unsigned a_bytes = (unsigned)(((long)(n_last - n_first + 1) * g.SH * g.SW - 1) * g.ld_src * 2 + (long)g.SC * 2);
+    rs_a = v3_make_srd(src + (long)n_first * g.SH * g.SW * g.ld_src, a_bytes);
+    wrow0 = (unsigned)(n0 + srow) * (unsigned)g.Kfull * 2u;
+    ta = 0; tb = 0; cb = 0;
+    retap();
+  };
+  auto issueA = [&](int slot) {
+    const unsigned base = lds0 + (unsigned)slot * V3_UNIT;
+    v3_dma16(base, aoff[0], rs_a, 0);
+    v3_dma16(base + 8192, aoff[1], rs_a, 0);
+  };
+  auto issueB = [&](int slot) {
+    const unsigned base = lds0 + (unsigned)slot * V3_UNIT + V3_ABYTES;
+    v3_dma16(base, boff, rs_b, 0);
+    v3_dma16(base + 8192, boff, rs_b, wj);
+  };
+  auto issueA1 = [&](int slot, int j) {
+    v3_dma16(lds0 + (unsigned)slot * V3_UNIT + (unsigned)j * 8192u, aoff[j], rs_a, 0);
+  };
+  auto issueB1 = [&](int slot, int j) {
+    v3_dma16(lds0 + (unsigned)slot * V3_UNIT + V3_ABYTES + (unsigned)j * 8192u, boff, rs_b, j == 0 ? 0 : wj);
+  };
+
+  // ---- fragment addressing (bytes inside a unit): row fr (+16 i), k chunk fq at slot fq ^ G[fr]
+  const int fr = lane & 15, fq = lane >> 4;
+  const int a_rd = (wm0 + fr) * 64 + ((fq ^ v3p_swz(fr)) << 4);
+  const int b_rd = V3_ABYTES + (wn0 + fr) * 64 + ((fq ^ v3p_swz(fr)) << 4);
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ac[4], an[4], bc[TN], bn[TN];
+
+  const int KU = g.Ktot / V3_BK;
+  auto rdA = [&](int slot, int mh, bf16x8 (&af)[4]) {
+    const unsigned char* s = smem + slot * V3_UNIT + a_rd + mh * 4 * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(s + i * 1024);
+  };
+  auto rdB = [&](int slot, bf16x8 (&bf)[TN]) {
+    const unsigned char* s = smem + slot * V3_UNIT + b_rd;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const bf16x8*>(s + i * 1024);
+  };
+  auto mma8 = [&](auto MH_, auto Q_, bf16x8 (&af)[4], bf16x8 (&bf)[TN]) {
+    constexpr int MH = decltype(MH_)::value, Q = decltype(Q_)::value;
+#pragma unroll
+    for (int j = 2 * Q; j < 2 * Q + 2; ++j)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        acc[i][MH * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][MH * 4 + j], 0, 0, 0);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  // one unit of the K loop, exactly as in conv_bf16_v3.hip (pieces of unit u+3 spread over the unit, one barrier per unit)
+  auto unit = [&](int u, bf16x8 (&bcur)[TN], bf16x8 (&bnxt)[TN]) {
+    const int slot = u & 3, nslot = (u + 3) & 3;
+    __builtin_amdgcn_sched_barrier(0);
+    rdA(slot, 1, an);
+    issueA1(nslot, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(H0{}, H0{}, ac, bcur);
+    __builtin_amdgcn_sched_barrier(0);
+    issueA1(nslot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(H0{}, H1{}, ac, bcur);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    rdB((u + 1) & 3, bnxt);
+    rdA((u + 1) & 3, 0, ac);
+    issueB1(nslot, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(H1{}, H0{}, an, bcur);
+    __builtin_amdgcn_sched_barrier(0);
+    issueB1(nslot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma8(H1{}, H1{}, an, bcur);
+    __builtin_amdgcn_sched_barrier(0);
+    advance();
+  };
+
+  // ---- epilogue of the tile at (em0, en0), from registers
+  const bool even = (fq & 1) == 0;
+  const int cb0 = even ? 4 * fq : 16 + 4 * (fq - 1);        // after the lane-row swap: this lane's 8 consecutive channels of a 32-channel pair
+  auto epilogue = [&](long em0, int en0) {
+    if (!DGRAD && (g.flags & GF_STATS)) {                    // BatchNorm chunk partials: this wave owns one 128-row chunk x 64 channels
+      const long crow0 = em0 + wm0;
+      if (crow0 < g.M) {
+        const bool full = crow0 + 128 <= g.M;
+        float* pp = g.stat_part + (crow0 >> 7) * 3 * (long)g.NC;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          f32x4 kk, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) kk[e] = __shfl(acc[i][0][e], lane & 48, 64);     // the chunk's first row (pixel 0 of tile 0)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            f32x4 d = acc[i][j] - kk;
+            if (!full) { if (crow0 + j * 16 + fr >= g.M) d = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            s1 += d;
+            s2 = __builtin_elementwise_fma(d, d, s2);
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+          }
+          const int n = en0 + wn0 + i * 16 + 4 * fq;
+          if (fr == 0) {
+            *reinterpret_cast<f32x4*>(pp + n) = s1;
+            *reinterpret_cast<f32x4*>(pp + g.NC + n) = s2;
+            *reinterpret_cast<f32x4*>(pp + 2 * (long)g.NC + n) = kk;
+          }
+        }
+      }
+    }
+    const bool accum = g.flags & GF_ACCUM;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const long m = em0 + wm0 + 16 * j + fr;
+      const bool ok = m < g.M;
+      long pix = m;
+      if (DGRAD && g.step > 1 && ok) {                        // parity class of a strided data gradient: scattered destination pixel
+        const int nn = (int)(((unsigned long long)(unsigned)m * g.mg_ohw) >> g.sh_ohw);
+        const int rem = (int)m - nn * ohw;
+        const int ii = (int)(((unsigned long long)(unsigned)rem * g.mg_ow) >> g.sh_ow), jj = rem - ii * g.OWs;
+        pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        f32x4 v0, v1;
+        // v_permlane16_swap: the odd 16-lane rows of the first register trade places with the even rows of the second -> 8 consecutive
+        // channels per lane (conv_c64_bf16.hip's epilogue idiom; same C/D layout: weight fragment first, a lane = 4 channels of a pixel)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][j][e]), __float_as_uint(acc[2 * p + 1][j][e]), false, false);
+          v0[e] = __uint_as_float(sw[0]); v1[e] = __uint_as_float(sw[1]);
+        }
+        if (ok) {
+          __bf16* dp = dst + pix * g.ld_dst + en0 + wn0 + 32 * p + cb0;
+          if (accum) {
+            const bf16x8 old = *reinterpret_cast<const bf16x8*>(dp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] += (float)old[e]; v1[e] += (float)old[4 + e]; }
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = (__bf16)v0[e]; o[4 + e] = (__bf16)v1[e]; }
+          *reinterpret_cast<bf16x8*>(dp) = o;
+        }
+      }
+    }
+  };
+
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);               // static priority for the second-dispatched half (as conv_bf16_v3.hip)
+  setup(tbase + tk);
+  if (KU > 0) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { issueA(u); issueB(u); advance(); }
+  }
+  for (;;) {
+    const long em0 = m0;
+    const int en0 = n0;
+    if (KU > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // units 0..2 of this tile (and the previous tile's stores) have landed
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      rdB(0, bc);
+      rdA(0, 0, ac);
+      int u = 0;
+      for (; u + 1 < KU; u += 2) {
+        unit(u, bc, bn);
+        unit(u + 1, bn, bc);
+      }
+      if (u < KU) unit(u, bc, bn);
+      // the pipeline's tail pieces (zeros into consumed slots) must have landed before the next tile's first units go into the ring
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tk += wstride;
+    const bool more = tk < tcount;
+    __builtin_amdgcn_s_barrier();                              // every wave has read its last fragments: the ring is free
+    if (more) {
+      setup(tbase + tk);
+      if (KU > 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { issueA(u); issueB(u); advance(); }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    epilogue(em0, en0);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!more) break;
+  }
+}
+
+bool gather_bf16_v3p_ok(const GatherGeom& g) {
+  return edrl_cfg().bf16_v3_persist != 0 && g.M < 0x7fffffff;
+}
+
+int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const GatherGeom& g0, bool dgrad, hipStream_t st) {
+  GatherGeom g = g0;
+  gather_geom_magic(&g);
+  const int tiles_m = edrl_cdiv(g.M, V3_BM), tiles_n = edrl_cdiv(g.NC, V3_BN);
+  const long nt = (long)tiles_m * tiles_n;
+  if (nt <= 0) return 0;
+  if (nt > 0x7fffffffL) return EDRL_EINVAL;
+  if (((uintptr_t)src & 15) || ((uintptr_t)wm & 15) || ((uintptr_t)dst & 15)) return EDRL_EINVAL;
+  int grid = nt >= 256 ? 256 : (int)((nt + 7) / 8 * 8);      // one workgroup per CU; a multiple of 8 (XCD-contiguous tile ranges)
+  static bool attr_set[2] = {false, false};
+  if (dgrad) {
+    auto kern = conv_gather_bf16_v3p_kernel<true>;
+    if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[1] = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt);
+  } else {
+    auto kern = conv_gather_bf16_v3p_kernel<false>;
+    if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[0] = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt);
+  }
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}

@@ -29,7 +29,9 @@ def timeit(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-MODES = {"old": {"EDRL_BF16_V3": "0", "EDRL_V3_STAGGER": "0"}, "v3": {"EDRL_BF16_V3": "2", "EDRL_V3_STAGGER": "0"}, "v3stag": {"EDRL_BF16_V3": "2", "EDRL_V3_STAGGER": "1"}}
+# third column (round 4): the persistent form of the v3 core (conv_bf16_v3p.hip; round 3 listed the staggered variant there)
+MODES = {"old": {"EDRL_BF16_V3": "0", "EDRL_BF16_V3_PERSIST": "0"}, "v3": {"EDRL_BF16_V3": "2", "EDRL_BF16_V3_PERSIST": "0"},
+         "v3stag": {"EDRL_BF16_V3": "2", "EDRL_BF16_V3_PERSIST": "1"}}
 
 
 def setmode(m):
@@ -54,7 +56,7 @@ def run(mode, fn):
     return o
 
 
-print(f"{'layer':20s} {'GFLOP':>7s} | fwd ms (TF): 128-row kernel, v3, v3 staggered | dgrad ms (TF): same three | max rel diff vs the 128-row kernel: fwd v3/stag, stats, dgrad v3/stag")
+print(f"{'layer':20s} {'GFLOP':>7s} | fwd ms (TF): 128-row kernel, v3 (one tile per workgroup), v3 persistent | dgrad ms (TF): same three | max rel diff vs the 128-row kernel: fwd v3/stag, stats, dgrad v3/stag")
 tot = {}
 for name, Ci, H, Co, k, s, p, cnt in L:
     if only and only not in name:

@@ -67,11 +67,15 @@ V3_CASES = [
     (2, 512, 10, 10, 256, 1, 2, 0),
     (1, 256, 7, 7, 256, 3, 1, 1),
     (4, 1024, 6, 5, 256, 1, 1, 0),
+    (16, 64, 70, 70, 256, 1, 1, 0),      # 307 tiles: more than one tile per workgroup in the persistent form (forward)
+    (20, 256, 64, 64, 256, 1, 1, 0),     # 320 tiles, forward + data gradient (plain and accumulating)
+    (9, 256, 62, 62, 256, 3, 2, 1),      # stride 2: four parity classes of 34 tiles each, ragged
 ]
 
 
+@pytest.mark.parametrize("persist", ["1", "0"])
 @pytest.mark.parametrize("case", V3_CASES)
-def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, switches):
+def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, persist, switches):
     """The 256x256 LDS-DMA core (csrc/conv_bf16_v3.hip), forced on (EDRL_BF16_V3=2) at sizes far below its production range:
     forward (+ fused BatchNorm chunk partials), data gradient (plain, accumulating, stride-2 parity classes) against the fp64
     convolution of the same bf16 operands at one bf16 ulp of the output range, the chunk partials against sums taken from the
@@ -90,6 +94,7 @@ def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, switches):
     y.backward(dy.double())
     Ho, Wo = y.shape[2], y.shape[3]
     outs = {}
+    switches(EDRL_BF16_V3_PERSIST=persist)      # "1": the persistent form (conv_bf16_v3p.hip: register epilogue, next tile prefetched)
     for mode in ("0", "2"):
         switches(EDRL_BF16_V3=mode)
         yh, part, chunks = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), s, p, stats=True)
