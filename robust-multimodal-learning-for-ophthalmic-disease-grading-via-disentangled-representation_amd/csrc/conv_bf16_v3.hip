@@ -517,8 +517,10 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
 #else
   const bool diag = false;
 #endif
-  if (!(fuse && fuse->ep_x) && !diag && edrl_cfg().v3_stagger != 1 && gather_bf16_v3p_ok(g))
-    return launch_gather_bf16_v3p(src, wm, dst, g, dgrad, st);      // plain forward / data gradient: the persistent form
+  if (!diag && edrl_cfg().v3_stagger != 1 && gather_bf16_v3p_ok(g)) {      // the persistent form (conv_bf16_v3p.hip)
+    if (fuse && fuse->ep_x && (!dgrad || !gather_bf16_v3_epi_ok(g, *fuse))) return EDRL_EINVAL;
+    return launch_gather_bf16_v3p(src, wm, dst, g, dgrad, st, fuse);
+  }
 
   if (fuse && fuse->ep_x) {      // data gradient with the BatchNorm-backward epilogue (mask + partial sums)
     if (!dgrad || !gather_bf16_v3_epi_ok(g, *fuse)) return EDRL_EINVAL;

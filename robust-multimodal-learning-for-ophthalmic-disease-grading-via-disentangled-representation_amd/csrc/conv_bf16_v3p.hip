@@ -9,8 +9,8 @@
 // In-kernel stamps of round 3 (profiles/r03_v3_dma_ablation.txt): prologue 9.5 k + epilogue 7.1 k cycles of 119 k per `l3 3x3 256`
 // tile with nothing overlapping them (one workgroup per CU).  Tiles are dealt so that the tiles of one XCD stay a contiguous range
 // (operand panels shared in that XCD's L2), 32 workgroups per XCD striding through it.
-// Plain forward / data gradient only (GF_STATS, GF_ACCUM, strided parity classes); the BatchNorm-backward epilogue (EPI 1) stays on
-// the one-tile-per-workgroup kernel, whose cross-wave reduction needs the LDS anyway.  EDRL_BF16_V3_PERSIST=0: off.
+// Forward / data gradient (GF_STATS, GF_ACCUM, strided parity classes) and the data gradient with the BatchNorm-backward epilogue
+// (EPI 1, see the template).  EDRL_BF16_V3_PERSIST=0: the one-tile-per-workgroup kernel of conv_bf16_v3.hip instead.
 #include "edrl_common.h"
 #include "edrl_config.h"
 #include <stdlib.h>
@@ -36,9 +36,15 @@ __device__ __forceinline__ int v3p_swz(int r) {
   return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
 }
 
-template <bool DGRAD>
+// EPI 1 (data gradient): the BatchNorm-backward epilogue of conv_bf16_v3.hip in registers.  A wave owns one 128-row chunk x 64
+// channels, so the chunk partial sums (sum g, sum g*(x - mean)) need no cross-wave step: per lane over its 8 pixel tiles, then
+// over the 16 pixel lanes of each lane row -> ep_part [ep_chunk0 + row / 128][2][NC].  (Unlike the LDS-staged epilogue of the
+// one-tile kernel, which sums the values after their bf16 staging, this one sums the fp32 values before any rounding -- what
+// the 128-row kernel does.)
+template <bool DGRAD, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf16* __restrict__ src, const __bf16* __restrict__ wm,
-                                                                      __bf16* __restrict__ dst, GatherGeom g, int tiles_n, int ntiles) {
+                                                                      __bf16* __restrict__ dst, GatherGeom g, int tiles_n, int ntiles,
+                                                                      GatherFuse F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = 8, TN = 4;                 // wave tile 128 pixels x 64 channels of 16x16 MFMA tiles
   const int tid = threadIdx.x, lane = tid & 63;
@@ -244,6 +250,16 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
       }
     }
     const bool accum = g.flags & GF_ACCUM;
+    // EPI 1 operands of this lane's 2 x 8 channels
+    const __bf16* epx = reinterpret_cast<const __bf16*>(F.ep_x);
+    const bool use_mask = EPI != 0 && F.ep_mask != nullptr;
+    const bool use_relu = EPI != 0 && !use_mask && (g.flags & GF_EPI_RELU);
+    const int nq = g.NC >> 2;
+    f32x4 s0[EPI ? 4 : 1], s1[EPI ? 4 : 1];        // [2 p + h]: sums of channels 32 p + cb0 + 4 h .. +3
+    if constexpr (EPI != 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s0[q] = s1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const long m = em0 + wm0 + 16 * j + fr;
@@ -266,17 +282,61 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
           v0[e] = __uint_as_float(sw[0]); v1[e] = __uint_as_float(sw[1]);
         }
         if (ok) {
-          __bf16* dp = dst + pix * g.ld_dst + en0 + wn0 + 32 * p + cb0;
+          const int chan = en0 + wn0 + 32 * p + cb0;
+          __bf16* dp = dst + pix * g.ld_dst + chan;
           if (accum) {
             const bf16x8 old = *reinterpret_cast<const bf16x8*>(dp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] += (float)old[e]; v1[e] += (float)old[4 + e]; }
+          }
+          if constexpr (EPI != 0) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(epx + pix * F.ld_ep + chan);
+            unsigned mb = 0xffffu;
+            if (use_mask) mb = *reinterpret_cast<const unsigned short*>(F.ep_mask + pix * nq + (chan >> 2));
+            const f32x4 mu0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan), mu1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan + 4);
+            f32x4 sc0 = mu0, sc1 = mu0, sh0 = mu0, sh1 = mu0;
+            if (use_relu) {
+              sc0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan); sc1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan + 4);
+              sh0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + chan); sh1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + chan + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x0 = (float)xv[e], x1 = (float)xv[4 + e];
+              const bool k0 = use_mask ? ((mb >> e) & 1u) != 0u : (use_relu ? __builtin_fmaf(x0, sc0[e], sh0[e]) > 0.f : true);
+              const bool k1 = use_mask ? ((mb >> (8 + e)) & 1u) != 0u : (use_relu ? __builtin_fmaf(x1, sc1[e], sh1[e]) > 0.f : true);
+              v0[e] = k0 ? v0[e] : 0.f;
+              v1[e] = k1 ? v1[e] : 0.f;
+              s0[2 * p][e] += v0[e]; s1[2 * p][e] = __builtin_fmaf(v0[e], x0 - mu0[e], s1[2 * p][e]);
+              s0[2 * p + 1][e] += v1[e]; s1[2 * p + 1][e] = __builtin_fmaf(v1[e], x1 - mu1[e], s1[2 * p + 1][e]);
+            }
           }
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o[e] = (__bf16)v0[e]; o[4 + e] = (__bf16)v1[e]; }
           *reinterpret_cast<bf16x8*>(dp) = o;
         }
+      }
+    }
+    if constexpr (EPI != 0) {
+      // sum over the 16 pixel lanes of this lane row (xor 1, 2, 4, 8 stay inside it); lane fr == 0 writes its 16 channels
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { s0[q][e] += __shfl_xor(s0[q][e], o, 64); s1[q][e] += __shfl_xor(s1[q][e], o, 64); }
+        }
+      const long crow0 = em0 + wm0;
+      if (fr == 0 && crow0 < g.M) {
+        float* pp = F.ep_part + ((long)F.ep_chunk0 + (crow0 >> 7)) * 2 * g.NC;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int chan = en0 + wn0 + 32 * p + cb0 + 4 * h;
+            *reinterpret_cast<f32x4*>(pp + chan) = s0[2 * p + h];
+            *reinterpret_cast<f32x4*>(pp + g.NC + chan) = s1[2 * p + h];
+          }
       }
     }
   };
@@ -330,7 +390,8 @@ bool gather_bf16_v3p_ok(const GatherGeom& g) {
   return edrl_cfg().bf16_v3_persist != 0 && g.M < 0x7fffffff;
 }
 
-int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const GatherGeom& g0, bool dgrad, hipStream_t st) {
+int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const GatherGeom& g0, bool dgrad, hipStream_t st,
+                           const GatherFuse* fuse) {
   GatherGeom g = g0;
   gather_geom_magic(&g);
   const int tiles_m = edrl_cdiv(g.M, V3_BM), tiles_n = edrl_cdiv(g.NC, V3_BN);
@@ -339,15 +400,25 @@ int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const Gat
   if (nt > 0x7fffffffL) return EDRL_EINVAL;
   if (((uintptr_t)src & 15) || ((uintptr_t)wm & 15) || ((uintptr_t)dst & 15)) return EDRL_EINVAL;
   int grid = nt >= 256 ? 256 : (int)((nt + 7) / 8 * 8);      // one workgroup per CU; a multiple of 8 (XCD-contiguous tile ranges)
-  static bool attr_set[2] = {false, false};
+  static bool attr_set[3] = {false, false, false};
+  GatherFuse F;
+  memset(&F, 0, sizeof(F));
+  if (fuse && fuse->ep_x) {
+    if (!dgrad) return EDRL_EINVAL;
+    auto kern = conv_gather_bf16_v3p_kernel<true, 1>;
+    if (!attr_set[2]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[2] = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt, *fuse);
+    EDRL_LAUNCH_CHECK();
+    return 0;
+  }
   if (dgrad) {
     auto kern = conv_gather_bf16_v3p_kernel<true>;
     if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[1] = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt, F);
   } else {
     auto kern = conv_gather_bf16_v3p_kernel<false>;
     if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[0] = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt, F);
   }
   EDRL_LAUNCH_CHECK();
   return 0;

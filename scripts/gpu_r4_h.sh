@@ -1,0 +1,23 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_canary.py -m gpu -q --timeout 600 -p no:cacheprovider -x > gpurun_out/r4h_pytest.log 2>&1
+rc=$?; echo "pytest exit=$rc" >> gpurun_out/r4h_pytest.log; tail -4 gpurun_out/r4h_pytest.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 600 python -m pytest tests/test_gpu_head.py tests/test_gpu_fullsize.py -m gpu -q --timeout 600 -p no:cacheprovider -k "bf16 or c2 or c4 or C2 or C4" > gpurun_out/r4h_pytest2.log 2>&1
+echo "pytest2 exit=$?" >> gpurun_out/r4h_pytest2.log; tail -3 gpurun_out/r4h_pytest2.log
+for v in 1; do
+  EDRL_BF16_V3_PERSIST=$v timeout -k 10 300 python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-recompute-leg > gpurun_out/r4h_c2.json 2>/dev/null
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/r4h_c2.json"))
+print("persist=$v value", d["value"], "ms", d["ms_per_step"], "overlap", d.get("view_overlap",{}).get("value"), {k:round(x["ms_total"]/5,1) for k,x in d["kernels"].items()})
+PY
+done
+timeout -k 10 300 python bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline --no-recompute-leg --no-overlap-leg > gpurun_out/r4h_c4.json 2>/dev/null
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r4h_c4.json"))
+print("C4 value", d["value"], "ms", d["ms_per_step"], "mem", d["peak_mem_GiB"])
+PY
+exit 0

@@ -720,11 +720,14 @@ V3_EPI_CASES = [
     (1, 7, 7, 256, 256, 3, 1, 1, False, True),         # less than one 128-row chunk
     (5, 9, 7, 256, 1024, 1, 1, 0, True, False),
     (2, 12, 12, 512, 256, 1, 2, 0, True, True),        # 1x1 stride 2: three of the four classes have no tap (epilogue only)
+    (20, 64, 64, 256, 256, 1, 1, 0, True, True),       # 320 tiles: several tiles per workgroup in the persistent form
+    (18, 62, 62, 256, 256, 3, 1, 1, False, False),     # 271 tiles, ragged last tile, decision recomputed
 ]
 
 
+@pytest.mark.parametrize("persist", ["1", "0"])
 @pytest.mark.parametrize("case", V3_EPI_CASES)
-def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, switches):
+def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, persist, switches):
     """The BatchNorm-backward epilogue of the 256x256 LDS-DMA data-gradient core (conv_bf16_v3.hip EPI 1: accumulate, mask with
     the sign bytes / the recomputed ReLU decision of the BatchNorm below, (sum g, sum g*(x - mean)) per 128-row chunk), forced on
     far below its production sizes: the masked gradient against fp64 at one bf16 ulp (two with accumulate), every chunk's partial
@@ -754,6 +757,7 @@ def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, switc
     care = torch.ones_like(keep) if use_mask else (pre.abs() > 1e-6 * pre.abs().max())
     wt = ops.permute_weight_bf16(w.float().to(dev))
     outs = {}
+    switches(EDRL_BF16_V3_PERSIST=persist)      # "1": conv_bf16_v3p.hip (register epilogue, per-wave chunk sums), "0": conv_bf16_v3.hip
     for mode in ("0", "2"):
         switches(EDRL_BF16_V3=mode)
         dst = old.clone().to(dev) if accum else None
