@@ -47,6 +47,6 @@ int launch_conv1x1_k64_bwd(const void* g, const void* yraw, const float* bcoef, 
 
 // Persistent form of the core (conv_bf16_v3p.hip: next tile's first units issued before the epilogue, register epilogue): plain
 // forward / data gradient (GF_STATS, GF_ACCUM, strided classes); same geometry conditions as gather_bf16_v3_ok.
-bool gather_bf16_v3p_ok(const GatherGeom& g);
+bool gather_bf16_v3p_ok(const GatherGeom& g, bool epi);
 int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st,
                            const GatherFuse* fuse = nullptr);

@@ -517,7 +517,7 @@ int launch_gather_bf16_v3(const void* src, const void* wm, void* dst, const Gath
 #else
   const bool diag = false;
 #endif
-  if (!diag && edrl_cfg().v3_stagger != 1 && gather_bf16_v3p_ok(g)) {      // the persistent form (conv_bf16_v3p.hip)
+  if (!diag && edrl_cfg().v3_stagger != 1 && gather_bf16_v3p_ok(g, fuse && fuse->ep_x)) {      // the persistent form (conv_bf16_v3p.hip)
     if (fuse && fuse->ep_x && (!dgrad || !gather_bf16_v3_epi_ok(g, *fuse))) return EDRL_EINVAL;
     return launch_gather_bf16_v3p(src, wm, dst, g, dgrad, st, fuse);
   }

@@ -260,60 +260,82 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
 #pragma unroll
       for (int q = 0; q < 4; ++q) s0[q] = s1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // destination pixel of each of the lane's 8 rows (a strided class scatters them)
+    long pixs[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const long m = em0 + wm0 + 16 * j + fr;
-      const bool ok = m < g.M;
       long pix = m;
-      if (DGRAD && g.step > 1 && ok) {                        // parity class of a strided data gradient: scattered destination pixel
+      if (DGRAD && g.step > 1 && m < g.M) {                   // parity class of a strided data gradient: scattered destination pixel
         const int nn = (int)(((unsigned long long)(unsigned)m * g.mg_ohw) >> g.sh_ohw);
         const int rem = (int)m - nn * ohw;
         const int ii = (int)(((unsigned long long)(unsigned)rem * g.mg_ow) >> g.sh_ow), jj = rem - ii * g.OWs;
         pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
       }
+      pixs[j] = m < g.M ? pix : -1;
+    }
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        f32x4 v0, v1;
-        // v_permlane16_swap: the odd 16-lane rows of the first register trade places with the even rows of the second -> 8 consecutive
-        // channels per lane (conv_c64_bf16.hip's epilogue idiom; same C/D layout: weight fragment first, a lane = 4 channels of a pixel)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][j][e]), __float_as_uint(acc[2 * p + 1][j][e]), false, false);
-          v0[e] = __uint_as_float(sw[0]); v1[e] = __uint_as_float(sw[1]);
+    for (int p = 0; p < 2; ++p) {
+      const int chan = en0 + wn0 + 32 * p + cb0;
+      f32x4 mu0 = {0.f, 0.f, 0.f, 0.f}, mu1 = mu0, sc0 = mu0, sc1 = mu0, sh0 = mu0, sh1 = mu0;
+      if constexpr (EPI != 0) {
+        mu0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan); mu1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan + 4);
+        if (use_relu) {
+          sc0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan); sc1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan + 4);
+          sh0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + chan); sh1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + chan + 4);
         }
-        if (ok) {
-          const int chan = en0 + wn0 + 32 * p + cb0;
-          __bf16* dp = dst + pix * g.ld_dst + chan;
-          if (accum) {
-            const bf16x8 old = *reinterpret_cast<const bf16x8*>(dp);
+      }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] += (float)old[e]; v1[e] += (float)old[4 + e]; }
-          }
-          if constexpr (EPI != 0) {
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(epx + pix * F.ld_ep + chan);
-            unsigned mb = 0xffffu;
-            if (use_mask) mb = *reinterpret_cast<const unsigned short*>(F.ep_mask + pix * nq + (chan >> 2));
-            const f32x4 mu0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan), mu1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan + 4);
-            f32x4 sc0 = mu0, sc1 = mu0, sh0 = mu0, sh1 = mu0;
-            if (use_relu) {
-              sc0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan); sc1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan + 4);
-              sh0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + chan); sh1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 4 * (long)g.NC + chan + 4);
-            }
+      for (int jh = 0; jh < 2; ++jh) {
+        // the global operands of 4 rows requested together (read-modify-write target, raw tensor, sign bytes)
+        bf16x8 oldv[4], xv[4];
+        unsigned mb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x0 = (float)xv[e], x1 = (float)xv[4 + e];
-              const bool k0 = use_mask ? ((mb >> e) & 1u) != 0u : (use_relu ? __builtin_fmaf(x0, sc0[e], sh0[e]) > 0.f : true);
-              const bool k1 = use_mask ? ((mb >> (8 + e)) & 1u) != 0u : (use_relu ? __builtin_fmaf(x1, sc1[e], sh1[e]) > 0.f : true);
-              v0[e] = k0 ? v0[e] : 0.f;
-              v1[e] = k1 ? v1[e] : 0.f;
-              s0[2 * p][e] += v0[e]; s1[2 * p][e] = __builtin_fmaf(v0[e], x0 - mu0[e], s1[2 * p][e]);
-              s0[2 * p + 1][e] += v1[e]; s1[2 * p + 1][e] = __builtin_fmaf(v1[e], x1 - mu1[e], s1[2 * p + 1][e]);
+        for (int q = 0; q < 4; ++q) {
+          const long pix = pixs[4 * jh + q];
+          mb[q] = 0xffffu;
+          if (pix >= 0) {
+            if (accum) oldv[q] = *reinterpret_cast<const bf16x8*>(dst + pix * g.ld_dst + chan);
+            if constexpr (EPI != 0) {
+              xv[q] = *reinterpret_cast<const bf16x8*>(epx + pix * F.ld_ep + chan);
+              if (use_mask) mb[q] = *reinterpret_cast<const unsigned short*>(F.ep_mask + pix * nq + (chan >> 2));
             }
           }
-          bf16x8 o;
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] = (__bf16)v0[e]; o[4 + e] = (__bf16)v1[e]; }
-          *reinterpret_cast<bf16x8*>(dp) = o;
+        for (int q = 0; q < 4; ++q) {
+          const int j = 4 * jh + q;
+          f32x4 v0, v1;
+          // v_permlane16_swap: the odd 16-lane rows of the first register trade places with the even rows of the second -> 8
+          // consecutive channels per lane (conv_c64_bf16.hip's epilogue idiom; same C/D layout: weight fragment first)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][j][e]), __float_as_uint(acc[2 * p + 1][j][e]), false, false);
+            v0[e] = __uint_as_float(sw[0]); v1[e] = __uint_as_float(sw[1]);
+          }
+          const long pix = pixs[j];
+          if (pix >= 0) {
+            if (accum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v0[e] += (float)oldv[q][e]; v1[e] += (float)oldv[q][4 + e]; }
+            }
+            if constexpr (EPI != 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x0 = (float)xv[q][e], x1 = (float)xv[q][4 + e];
+                const bool k0 = use_mask ? ((mb[q] >> e) & 1u) != 0u : (use_relu ? __builtin_fmaf(x0, sc0[e], sh0[e]) > 0.f : true);
+                const bool k1 = use_mask ? ((mb[q] >> (8 + e)) & 1u) != 0u : (use_relu ? __builtin_fmaf(x1, sc1[e], sh1[e]) > 0.f : true);
+                v0[e] = k0 ? v0[e] : 0.f;
+                v1[e] = k1 ? v1[e] : 0.f;
+                s0[2 * p][e] += v0[e]; s1[2 * p][e] = __builtin_fmaf(v0[e], x0 - mu0[e], s1[2 * p][e]);
+                s0[2 * p + 1][e] += v1[e]; s1[2 * p + 1][e] = __builtin_fmaf(v1[e], x1 - mu1[e], s1[2 * p + 1][e]);
+              }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (__bf16)v0[e]; o[4 + e] = (__bf16)v1[e]; }
+            *reinterpret_cast<bf16x8*>(dst + pix * g.ld_dst + chan) = o;
+          }
         }
       }
     }
@@ -386,8 +408,12 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
   }
 }
 
-bool gather_bf16_v3p_ok(const GatherGeom& g) {
-  return edrl_cfg().bf16_v3_persist != 0 && g.M < 0x7fffffff;
+// EDRL_BF16_V3_PERSIST: 0 off, 1 (default) forward / plain data gradient, 2 also the data gradient with the BatchNorm-backward
+// epilogue.  Measured at C2 (6 steps, same box): mode 1 320.4 ms per step, mode 2 324.9 -- the register epilogue touches 64-byte
+// segments of 16 pixel rows per instruction on THREE streams there (raw tensor, accumulate target, result), the LDS-staged
+// epilogue of conv_bf16_v3.hip whole 512-byte rows; with one stream (plain stores) the overlap with the next tile's loads wins.
+bool gather_bf16_v3p_ok(const GatherGeom& g, bool epi) {
+  return edrl_cfg().bf16_v3_persist >= (epi ? 2 : 1) && g.M < 0x7fffffff;
 }
 
 int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const GatherGeom& g0, bool dgrad, hipStream_t st,
