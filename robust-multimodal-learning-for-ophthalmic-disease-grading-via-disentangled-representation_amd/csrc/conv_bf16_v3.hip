@@ -489,9 +489,10 @@ bool gather_bf16_v3_ok(const GatherGeom& g, bool dgrad) {
                    (g.Ktot % V3_BK == 0);
   if (!can) return false;
   if (mode == 2) return true;
-  // Measured per layer against the 128-row kernel (scripts/v3_layer_bench.py, profiles/r03_v3_layers_bf16_2112img.txt): the forward
-  // wins from K = 512 up (3x3 convs, 1x1 convs with >= 512 input channels: +2..6 % at K = 512; K = 256 loses: one workgroup per
-  // CU cannot hide its prologue / epilogue behind so few K units); the data gradient wins at every K that occurs (>= 128), its
+  // Measured per layer against the 128-row kernel (scripts/v3_layer_bench.py, profiles/r04_v3_layers_bf16_2112img.txt): in its
+  // persistent form (conv_bf16_v3p.hip) the forward wins from K = 256 up (`l3 1x1 256->1024` 0.462 -> 0.425 ms; round 3's
+  // one-tile-per-workgroup form won from K = 512 only and lost at K = 256: nothing hid its prologue / epilogue behind 8 K units);
+  // K = 128 still loses (`l2 1x1 128->512` 0.505 vs 0.680 ms).  The data gradient wins at every K that occurs (>= 128), its
   // 128-row counterpart pays more for the scattered / accumulating epilogue.  Both need enough rows to fill the chip once.
   const int kmin_f = edrl_cfg().v3_fwd_kmin;
   return g.M >= 256 * 64 && g.Ktot >= (dgrad ? 128 : kmin_f);

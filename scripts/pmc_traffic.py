@@ -7,7 +7,8 @@ import csv, glob, json, sys, collections
 def family(name):
     """Kernel family of a dispatch: the bf16 kernels (C2/C4) are kept apart from the fp32 ones, and the 256x256 LDS-DMA core
     (conv_gather_bf16_v3, conv_wgrad_bf16_v3) apart from the 128-row / 128x128 bf16 kernels."""
-    for key in ("conv_gather_bf16_v3", "conv_gather_bf16", "conv_wgrad_bf16_v3", "conv_wgrad_bf16", "conv3x3_c64_bf16", "conv1x1_k64_bf16", "conv_gather", "conv_wgrad"):
+    for key in ("conv_gather_bf16_v3", "conv_gather_bf16", "conv_wgrad_bf16_v3", "conv_wgrad_bf16", "conv3x3_c64_bf16", "conv1x1_k64_bwd_bf16",
+                "conv1x1_k64_bf16", "conv_gather", "conv_wgrad"):
         if key in name:
             return key
     return None
@@ -76,6 +77,7 @@ if len(sys.argv) > 6:   # fourth pass: instruction mix (SQ_INSTS_VALU counts the
                                         # fp32 kernels only: 64 cycles per v_mfma_f32_32x32x2_f32 + 4 per other vector instruction, on the same lanes
                                         "pipe_bound_frac_of_peak": (64.0 / (64.0 + 4.0 * (c["SQ_INSTS_VALU"] - m) / m)) if "bf16" not in fam else None})
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k in ("conv_gather", "conv_wgrad", "conv_gather_bf16", "conv_gather_bf16_v3", "conv_wgrad_bf16", "conv_wgrad_bf16_v3", "conv3x3_c64_bf16", "conv1x1_k64_bf16"):
+for k in ("conv_gather", "conv_wgrad", "conv_gather_bf16", "conv_gather_bf16_v3", "conv_wgrad_bf16", "conv_wgrad_bf16_v3", "conv3x3_c64_bf16", "conv1x1_k64_bf16",
+          "conv1x1_k64_bwd_bf16"):
     if k in out["kernels"]:
         print(k, out["kernels"][k])
