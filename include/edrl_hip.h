@@ -419,6 +419,15 @@ int edrl_adam_chunk_elems(void);
 int edrl_adam_multi_f32(const void* tensors, int n_tensors, const void* chunks, int n_chunks, double lr, double beta1,
                         double beta2, double eps, double weight_decay, long step, hipStream_t stream);
 
+/* 3-D convolution forward over NDHWC volumes without the depth-unfolded copy (the true-3-D OCT encoder of SURVEY.md section 8f row 4;
+ * layer shapes of the reference's 3-D networks, baseline_models.py:154-178): x [N,Di,Hi,Wi,Ci], w [Co,KH,KW,KD*Ci] (the
+ * depth-unfolded weight layout, depth tap innermost of the taps), y [N,Do,Ho,Wo,Co]; depth stride / padding dstride / dpad,
+ * in-plane stride / pad.  Ci % 16 == 0, Co % 4 == 0, 16-byte aligned tensors, per-tile source footprint < 2 GiB:
+ * edrl_conv3d_fwd_ok_f32; callers fall back to edrl_depth_unfold_f32 + edrl_conv2d_nhwc_fwd_f32 otherwise (the 1-channel stem). */
+int edrl_conv3d_fwd_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW);
+int edrl_conv3d_ndhwc_fwd_f32(const float* x, const float* w, float* y, int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo,
+                              int Co, int KD, int KH, int KW, int dstride, int stride, int dpad, int pad, hipStream_t stream);
+
 /* Run-time switches (EDRL_* environment variables, csrc/edrl_config.h) are read ONCE at first use; this re-reads them.  For tests
  * and A/B scripts, between launches (not while other threads launch).  Returns 1 if the library was built with -DEDRL_DIAG
  * (diagnostic kernel variants present: libedrl_hip_diag.so), 0 for the shipped library. */

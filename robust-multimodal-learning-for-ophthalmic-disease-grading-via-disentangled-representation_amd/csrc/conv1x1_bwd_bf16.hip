@@ -21,13 +21,13 @@
 //   * d3 is formed once per element (fp32 fma, one rounding -- the arithmetic of conv_bf16.hip's ATR 2 operand) and written to an
 //     LDS image [64 px][256 co] whose 16-byte chunks are XOR-swizzled with S(row) = ((row&3)<<2)|((row>>2)&3): conflict-free BOTH
 //     for the row reads of the data gradient (ds_read_b128, 16 rows at one chunk per lane group) and for the transposing reads of the
-//     weight gradient (ds_read_b64_tr_b16, 4 rows x 4 chunks per 32-lane half); x2 goes to LDS raw, [64][64], swizzled likewise;
+//     weight gradient (ds_read_b64_tr_b16, 4 rows x 4 chunks per 32-lane half); a2 = relu(bn(x2)) is formed once per element and goes to LDS, [64][64], swizzled likewise;
 //   * data gradient: wave w owns pixels 32 (w>>1) .. +31 x channels 32 (w&1) .. +31, K = 256: 16 v_mfma_f32_32x32x16_bf16 with the
 //     weight fragment as first operand -> a lane holds 4 x 4 consecutive channels of ONE pixel; epilogue in registers: ReLU decision
-//     of bn2 recomputed from the raw x2 tile (same fma as the forward), masked gradient stored (8-byte pieces), partial sums kept
+//     of bn2 recomputed from the raw x2 values of its pixel (re-read from global: L2 hits; same fma as the forward), masked gradient stored (8-byte pieces), partial sums kept
 //     per lane for the whole launch and reduced once at the end -> ep_part [2 * workgroup + pixel block][2][64];
 //   * weight gradient: wave w owns output channels 64 w .. +63 x all 64 input channels, K = 64 pixels: 16 MFMAs on transposed
-//     fragments, a2 formed on the fragment (a lane owns ONE input channel of its 8 pixels); fp32 accumulators live in registers
+//     fragments of the d3 and a2 images; fp32 accumulators live in registers
 //     across all tiles of the workgroup -> one [256][64] slab per workgroup, summed in fixed order by splitk_reduce_h_kernel.
 // Deterministic: static tile -> workgroup assignment, ordered reductions, no atomics.
 #include "edrl_common.h"
@@ -45,7 +45,7 @@ typedef short b1_s16x4 __attribute__((ext_vector_type(4)));
 #define B1_NT 256                                  // threads per workgroup (4 waves; two workgroups per CU)
 #define B1_W_BYTES (16 * 2 * 64 * 16)              // 32 KiB: Wt fragments [k step][channel tile][lane]
 #define B1_D_BYTES (B1_P * B1_CO * 2)              // 32 KiB: d3 image
-#define B1_X_BYTES (B1_P * B1_CI * 2)              // 8 KiB: raw x2 image
+#define B1_X_BYTES (B1_P * B1_CI * 2)              // 8 KiB: a2 = relu(bn(x2)) image
 #define B1_T_BYTES ((3 * B1_CO + 3 * B1_CI) * 4)   // coefficient tables: A, nK2, C2 [256]; scale, shift2, mean [64]
 #define B1_LDS (B1_W_BYTES + B1_D_BYTES + B1_X_BYTES + B1_T_BYTES)
 
@@ -133,7 +133,6 @@ __global__ __launch_bounds__(B1_NT, 2) void conv1x1_k64_bwd_bf16_kernel(
   f32x4 es0[4], es1[4];                           // (sum g2, sum g2*(x2 - mean)) of this lane's 4 x 4 channels
 #pragma unroll
   for (int j = 0; j < 4; ++j) es0[j] = es1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float wsc[2] = {tsc[li], tsc[32 + li]}, wsh[2] = {tsh[li], tsh[32 + li]};     // weight gradient: this lane's input channel per tile
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long m0 = (long)tile * B1_P;
@@ -143,6 +142,19 @@ __global__ __launch_bounds__(B1_NT, 2) void conv1x1_k64_bwd_bf16_kernel(
     for (int i = 0; i < 8; ++i) issue(tile, i);
 #pragma unroll
     for (int i = 0; i < 2; ++i) issue_x(tile, i);
+    // raw x2 of this lane's epilogue pixel (4 x 4 channels): the LDS image holds the ACTIVATED tensor, the BatchNorm-backward sums
+    // need the raw one (L2 hits: the workgroup reads these lines for the staging pieces in the same breath)
+    b1_bf16x4 xe4[4];
+    {
+      const long m0e = (long)tile * B1_P;
+      long rows = (long)M - m0e; if (rows > B1_P) rows = B1_P;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x2 + m0e * B1_CI), 0, (int)(rows * B1_CI * 2), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(rx, ((32 * pb + li) * B1_CI + 32 * dct + 8 * j + 4 * lh) * 2, 0, 0);
+        xe4[j] = __builtin_bit_cast(b1_bf16x4, v2);
+      }
+    }
     // ---- consume the tile's pieces: d3 -> LDS, x2 raw -> LDS; each register is re-issued for the next tile as soon as it is read
     f32x4 cA[2], cK[2], cC[2];                    // A, nK2, C2 of this thread's 8 output channels (from the LDS table: no registers held
 #pragma unroll                                   //  across the multiply phase)
@@ -166,10 +178,17 @@ __global__ __launch_bounds__(B1_NT, 2) void conv1x1_k64_bwd_bf16_kernel(
       *reinterpret_cast<b1_bf16x8*>(dimg + row * (B1_CO * 2) + slot * 16) = d;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const b1_bf16x8 xv = X[i];
+    for (int i = 0; i < 2; ++i) {                 // a2 = relu(x2*scale + shift2), formed ONCE here (the weight gradient's operand)
       const int id = tid + B1_NT * i, row = id >> 3, chunk = id & 7;
-      *reinterpret_cast<b1_bf16x8*>(ximg + row * (B1_CI * 2) + ((chunk ^ b1_sx(row)) * 16)) = xv;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(tsc + chunk * 8), s1 = *reinterpret_cast<const f32x4*>(tsc + chunk * 8 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(tsh + chunk * 8), h1 = *reinterpret_cast<const f32x4*>(tsh + chunk * 8 + 4);
+      b1_bf16x8 av;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        av[e] = (__bf16)fmaxf(__builtin_fmaf((float)X[i][e], s0[e], h0[e]), 0.f);
+        av[4 + e] = (__bf16)fmaxf(__builtin_fmaf((float)X[i][4 + e], s1[e], h1[e]), 0.f);
+      }
+      *reinterpret_cast<b1_bf16x8*>(ximg + row * (B1_CI * 2) + ((chunk ^ b1_sx(row)) * 16)) = av;
     }
     __syncthreads();
 
@@ -194,14 +213,12 @@ __global__ __launch_bounds__(B1_NT, 2) void conv1x1_k64_bwd_bf16_kernel(
       const int prow = 32 * pb + li;
       const long m = m0 + prow;
       if (m < M) {
-        const int sx = b1_sx(prow);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int chunk = 4 * dct + j;
           const int cb = 32 * dct + 8 * j + 4 * lh;       // scale / shift2 / mean of these 4 channels: LDS table
           const f32x4 esc = *reinterpret_cast<const f32x4*>(tsc + cb), esh = *reinterpret_cast<const f32x4*>(tsh + cb);
           const f32x4 emu = *reinterpret_cast<const f32x4*>(tmu + cb);
-          const b1_bf16x4 xq = *reinterpret_cast<const b1_bf16x4*>(ximg + prow * (B1_CI * 2) + ((chunk ^ sx) * 16) + 8 * lh);
+          const b1_bf16x4 xq = xe4[j];
           b1_bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -222,11 +239,7 @@ __global__ __launch_bounds__(B1_NT, 2) void conv1x1_k64_bwd_bf16_kernel(
       const int cg = 16 * ((lane >> 4) & 1);
       b1_bf16x8 bf[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const b1_bf16x8 xr = b1_tr_frag<B1_CI * 2, false>(ximg, pix0, 32 * c + cg, lane);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bf[c][e] = (__bf16)fmaxf(__builtin_fmaf((float)xr[e], wsc[c], wsh[c]), 0.f);
-      }
+      for (int c = 0; c < 2; ++c) bf[c] = b1_tr_frag<B1_CI * 2, false>(ximg, pix0, 32 * c + cg, lane);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const b1_bf16x8 af = b1_tr_frag<B1_CO * 2, true>(dimg, pix0, 32 * (2 * wave + b) + cg, lane);

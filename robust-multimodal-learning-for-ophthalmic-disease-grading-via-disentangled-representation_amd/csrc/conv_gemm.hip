@@ -288,13 +288,15 @@ __device__ __forceinline__ u32x2 edrl_pack_bf16x4(f32x4 v) {
 // OUT16 (forward, EPI 0, vector epilogue, no accumulate / multiplier): `dst` is a bf16 tensor -- the fp32 result is rounded once
 // on the way out (BatchNorm partials still come from the fp32 accumulators).  The bf16 trunk's stem: fp32 image in, fp32 MFMA,
 // bf16 raw tensor out like every other layer of that trunk.
+// VOL (forward, BUF, ATR 0, EPI 0, MASK): 3-D convolution -- a third tap level (depth) in the row / tap decode, see GatherGeom.
 template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
-          bool OUT16 = false>
+          bool OUT16 = false, bool VOL = false>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherFuse F) {
   static_assert(ATR == 0 || BUF, "operand transforms ride on the buffer-descriptor path");
   static_assert(!OUT16 || (EPI == 0 && !DGRAD), "bf16 output: plain forward only");
+  static_assert(!VOL || (BUF && FAST && !DGRAD && ATR == 0 && EPI == 0 && MASK), "depth taps: plain forward on the descriptor path");
   constexpr unsigned EB = OUT16 ? 2u : 4u;     // bytes per destination element
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   const int k4 = (tid % KQ) * 4;
   const int r0 = tid / KQ;
   int rn[A_LD], rh[A_LD], rw[A_LD];
+  int rd[VOL ? A_LD : 1];                 // VOL: source depth of the row at depth tap 0 (do * dstride - dpad); rn = its source image
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const long m = m0 + r0 + RPP * i;
@@ -330,9 +333,14 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
       const int jj = rem - ii * g.OWs;
       const int oh = g.h0 + ii * g.step, ow = g.w0 + jj * g.step;
       rn[i] = n;
+      if constexpr (VOL) {                // n enumerates (sample, do): source image of depth tap kd = sample * SD + do * dstride - dpad + kd
+        const int smp = (int)(((unsigned long long)(unsigned)n * g.mg_od) >> g.sh_od);
+        rd[i] = (n - smp * g.OD) * g.dstride - g.dpad;
+        rn[i] = smp * g.SD + rd[i];
+      }
       if (DGRAD) { rh[i] = oh + g.pad; rw[i] = ow + g.pad; }
       else       { rh[i] = oh * g.stride - g.pad; rw[i] = ow * g.stride - g.pad; }
-    } else { rn[i] = -1; rh[i] = 0; rw[i] = 0; }
+    } else { rn[i] = -1; rh[i] = 0; rw[i] = 0; if constexpr (VOL) rd[i] = -(1 << 29); }
   }
   long wrow[B_LD];
 #pragma unroll
@@ -343,6 +351,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 
   // incremental decode of k = kt*BK + k4 -> (ta, tb, c): tap (kh0 + ta*kstep, kw0 + tb*kstep), channel c
   int c = k4, ta = 0, tb = 0, kk = k4;
+  int td = 0;          // VOL: depth tap (innermost tap level)
   while (c >= g.SC) { c -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } }
 
   // FAST (SC % BKT == 0): a K tile never straddles a tap, so every thread of the workgroup changes tap on the
@@ -360,7 +369,11 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const int ohw = g.OHs * g.OWs;
     long mlast = m0 + BM; if (mlast > g.M) mlast = g.M;
     n_first = (int)(((unsigned long long)(unsigned)m0 * g.mg_ohw) >> g.sh_ohw);
-    const int n_last = (int)(((unsigned long long)(unsigned)(mlast - 1) * g.mg_ohw) >> g.sh_ohw);
+    int n_last = (int)(((unsigned long long)(unsigned)(mlast - 1) * g.mg_ohw) >> g.sh_ohw);
+    if constexpr (VOL) {                  // descriptor over the whole volumes of the samples the tile's rows belong to
+      n_first = (int)(((unsigned long long)(unsigned)n_first * g.mg_od) >> g.sh_od) * g.SD;
+      n_last = (int)(((unsigned long long)(unsigned)n_last * g.mg_od) >> g.sh_od) * g.SD + g.SD - 1;
+    }
     const unsigned a_bytes = (unsigned)(((long)(n_last - n_first + 1) * g.SH * g.SW - 1) * g.ld_src * 4 + (long)g.SC * 4);
     rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)n_first * g.SH * g.SW * g.ld_src), 0, (int)a_bytes, 0x00020000);
     rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, (int)((long)g.NC * g.Kfull * 4), 0x00020000);
@@ -376,20 +389,20 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   }
   auto retap = [&]() {
     const int kh = g.kh0 + ta * g.kstep, kw = g.kw0 + tb * g.kstep;
-    tapoff = (long)(kh * g.KW + kw) * g.SC;
+    tapoff = VOL ? (long)((kh * g.KW + kw) * g.KD + td) * g.SC : (long)(kh * g.KW + kw) * g.SC;
     if constexpr (BUF) {
       const bool kvalid = ta < g.KHs && g.KWs > 0;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         int sh, sw;
-        bool ok = kvalid && rn[i] >= 0;
+        bool ok = kvalid && (VOL ? (unsigned)(rd[VOL ? i : 0] + td) < (unsigned)g.SD : rn[i] >= 0);
         if (DGRAD) {
           const int th = rh[i] - kh, tw = rw[i] - kw;
           ok = ok && th >= 0 && tw >= 0;
           sh = th >> g.sshift; sw = tw >> g.sshift;
         } else { sh = rh[i] + kh; sw = rw[i] + kw; }
         ok = ok && (unsigned)sh < (unsigned)g.SH && (unsigned)sw < (unsigned)g.SW;
-        const unsigned pix = (unsigned)(((rn[i] - n_first) * g.SH + sh) * g.SW + sw);
+        const unsigned pix = (unsigned)(((rn[i] + (VOL ? td : 0) - n_first) * g.SH + sh) * g.SW + sw);
         aoff[i] = ok ? pix * (unsigned)(g.ld_src * 4) + (unsigned)(cb + k4) * 4u : OOB;
       }
 #pragma unroll
@@ -414,7 +427,12 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   auto advance = [&]() {
     if constexpr (BUF) {   // the tap change is decided on the uniform part of the channel offset: a scalar branch
       cb += BKT;
-      if (cb >= g.SC) { cb -= g.SC; if (++tb == g.KWs) { tb = 0; ++ta; } retap(); }
+      if (cb >= g.SC) {
+        cb -= g.SC;
+        if constexpr (VOL) { if (++td == g.KD) { td = 0; if (++tb == g.KWs) { tb = 0; ++ta; } } }
+        else { if (++tb == g.KWs) { tb = 0; ++ta; } }
+        retap();
+      }
       else {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) aoff[i] += BKT * 4;
@@ -916,7 +934,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 }
 
 template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
-          bool OUT16 = false>
+          bool OUT16 = false, bool VOL = false>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
                             const float* mul, const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
@@ -924,7 +942,7 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI, MASK, OUT16>;
+  auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI, MASK, OUT16, VOL>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -934,6 +952,7 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   GatherGeom gm = g;
   gather_geom_magic(&gm);
+  if constexpr (VOL) gather_magic(g.OD > 0 ? (unsigned)g.OD : 1u, &gm.mg_od, &gm.sh_od);
   {   // strided parity class: the lean epilogue addresses the destination (and the EPI operands) through a descriptor based
       // at the first image a tile touches
     const long ohw = (long)g.OHs * g.OWs;
@@ -1617,6 +1636,40 @@ int edrl_conv2d_nhwc_fwd_f32(const float* x, const float* w, const float* bias, 
   g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
   g.stat_part = nullptr; g.stat_shift = nullptr;
   return dispatch_gather<false>(x, w, y, bias, mul, g, st);
+}
+
+// 3-D convolution forward over NDHWC volumes WITHOUT the depth-unfolded copy (shapes of the reference's
+// 3-D networks: baseline_models.py:154-178): the implicit-GEMM gather decodes a third tap level (conv_gather_f32_v2_kernel<..., VOL>).
+// x [N,Di,Hi,Wi,Ci], w [Co,KH,KW,KD*Ci] (depth tap innermost of the taps: the weight layout of the depth-unfolded form),
+// y [N,Do,Ho,Wo,Co].  Needs Ci % 16 == 0 (vector fast path), Co % 4 == 0, 16-byte aligned tensors; edrl_conv3d_fwd_ok_f32 tells.
+int edrl_conv3d_fwd_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW) {
+  if (N <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || KD <= 0 || KH <= 0 || KW <= 0) return 0;
+  if ((Ci % 16) || (Co % 4) || Ci <= 0 || Co <= 0) return 0;
+  const long ovol = (long)Do * Ho * Wo;
+  if ((long)N * ovol > 0x7fffffffL) return 0;
+  const long ktot = (long)KD * KH * KW * Ci;
+  if ((128 / ovol + 2) * (long)Di * Hi * Wi * Ci * 4 >= (1L << 31) || (long)Co * ktot * 4 >= (1L << 31)) return 0;
+  return 1;
+}
+int edrl_conv3d_ndhwc_fwd_f32(const float* x, const float* w, float* y, int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo,
+                              int Co, int KD, int KH, int KW, int dstride, int stride, int dpad, int pad, hipStream_t st) {
+  if (!x || !w || !y || dstride <= 0 || stride <= 0 || dpad < 0 || pad < 0) return EDRL_EINVAL;
+  if (!edrl_conv3d_fwd_ok_f32(N, Di, Hi, Wi, Ci, Do, Ho, Wo, Co, KD, KH, KW)) return EDRL_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return EDRL_EINVAL;
+  if ((long)(Ho - 1) * stride - pad + KH - 1 > (long)Hi - 1 + pad || (long)(Do - 1) * dstride - dpad + KD - 1 > (long)Di - 1 + dpad)
+    return EDRL_EINVAL;
+  GatherGeom g;
+  g.M = (int)((long)N * Do * Ho * Wo);
+  g.OH = Ho; g.OW = Wo; g.NC = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KD * KH * KW * Ci;
+  g.ld_src = Ci; g.ld_dst = Co; g.ld_aux = 0; g.flags = GF_VEC_EPI;
+  g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
+  g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
+  g.KD = KD; g.SD = Di; g.OD = Do; g.dstride = dstride; g.dpad = dpad;
+  const bool narrow = Co <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(Co, 128) < edrl_cfg().narrow_below);
+  if (narrow) return launch_gather_v2<128, 64, false, 16, 4, true, true, 0, 0, true, false, true>(x, w, y, nullptr, nullptr, g, st);
+  return launch_gather_v2<128, 128, false, 16, 4, true, true, 0, 0, true, false, true>(x, w, y, nullptr, nullptr, g, st);
 }
 
 // Convolution forward with the BatchNorm statistics of its output fused into the epilogue.

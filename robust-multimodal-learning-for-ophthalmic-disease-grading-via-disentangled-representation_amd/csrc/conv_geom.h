@@ -30,6 +30,12 @@ struct GatherGeom {
   // divisions in the row decode of every workgroup.
   unsigned mg_ohw, mg_ow;
   int sh_ohw, sh_ow;
+  // Depth taps (conv_gather_f32_v2_kernel<..., VOL = true> only: 3-D convolution over NDHWC volumes, csrc/vol_ops.hip; every other
+  // instantiation never reads these and their launchers leave them unset).  The row index enumerates (sample, do, oh, ow); K runs
+  // over (kh, kw, kd, ci) -- depth tap innermost of the taps, i.e. the weight layout [Co][KH][KW][KD*Ci] of the depth-unfolded form.
+  int KD, SD, OD, dstride, dpad;   // depth taps, source / destination depth, depth stride and padding
+  unsigned mg_od;                  // image index / OD (magic division, as above)
+  int sh_od;
 };
 
 static inline void gather_magic(unsigned d, unsigned* mg, int* sh) {

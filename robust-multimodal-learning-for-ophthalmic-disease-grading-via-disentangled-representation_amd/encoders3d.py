@@ -42,18 +42,30 @@ class Conv3dFn(torch.autograd.Function):
         x = ops._chk(x, "conv3d.x").contiguous()
         N, D, H, W, C = x.shape
         Co, KH, KW, CK = w.shape
-        xu = depth_unfold(x, KD, sd, pd, CK)
-        Do = xu.shape[1]
-        y = ops.conv2d_fwd(xu.view(N * Do, H, W, CK), w, stride=s, pad=p,
-                           alg_flops=2.0 * N * Do * ((H + 2 * p - KH) // s + 1) * ((W + 2 * p - KW) // s + 1) * Co * KH * KW * KD * C)
-        ctx.save_for_backward(xu, w)
+        Do = (D + 2 * pd - KD) // sd + 1
+        Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
+        flops = 2.0 * N * Do * Ho * Wo * Co * KH * KW * KD * C
         ctx.cfg = (tuple(x.shape), KD, sd, s, pd, p)
+        if CK == KD * C and L.query("edrl_conv3d_fwd_ok_f32", N, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW):
+            # depth taps decoded inside the implicit-GEMM gather: no k_d x unfolded copy, the volume itself is what backward keeps
+            y = torch.empty((N, Do, Ho, Wo, Co), device=x.device, dtype=torch.float32)
+            ops._launch_timed("conv_gather", flops, "edrl_conv3d_ndhwc_fwd_f32", P(x), P(w), P(y), N, D, H, W, C, Do, Ho, Wo, Co, KD, KH,
+                              KW, sd, s, pd, p, nbytes=4.0 * (x.numel() + w.numel() + y.numel()))
+            ctx.save_for_backward(x, w)
+            ctx.unfolded = False
+            return y
+        xu = depth_unfold(x, KD, sd, pd, CK)               # (the 1-channel stem: K = 7 taps padded to 8 columns)
+        y = ops.conv2d_fwd(xu.view(N * Do, H, W, CK), w, stride=s, pad=p, alg_flops=flops)
+        ctx.save_for_backward(xu, w)
+        ctx.unfolded = True
         return y.view(N, Do, y.shape[1], y.shape[2], Co)
 
     @staticmethod
     def backward(ctx, dy):
         xu, w = ctx.saved_tensors
         x_shape, KD, sd, s, pd, p = ctx.cfg
+        if not ctx.unfolded:                               # the unfolded operand of the weight gradient is rebuilt here, transiently
+            xu = depth_unfold(xu, KD, sd, pd, w.shape[3])
         N, Do, H, W, CK = xu.shape
         dy4 = dy.contiguous().view(N * Do, dy.shape[2], dy.shape[3], dy.shape[4])
         xu4 = xu.view(N * Do, H, W, CK)

@@ -13,4 +13,5 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "S
 done
 DESC=$(python3 -c "import sys; sys.path.insert(0,'$R'); import bench; print(bench.CONFIGS['$CFG'][5])")
 cd $R && python scripts/pmc_traffic.py gpurun_out/pmc_${CFG}_FETCH_SIZE gpurun_out/pmc_${CFG}_WRITE_SIZE gpurun_out/pmc_traffic_${CFG}.json "$DESC" gpurun_out/pmc_${CFG}_SQ_VALU_MFMA_BUSY_CYCLES gpurun_out/pmc_${CFG}_SQ_INSTS_VALU
-find gpurun_out/pmc_${CFG}_* -name "*.csv" -size +20M -delete
+# raw counter CSVs are tens of MB each; gpurun copies back at most 64 MiB: keep the reduced JSON and the logs only
+rm -rf gpurun_out/pmc_${CFG}_FETCH_SIZE gpurun_out/pmc_${CFG}_WRITE_SIZE gpurun_out/pmc_${CFG}_SQ_VALU_MFMA_BUSY_CYCLES gpurun_out/pmc_${CFG}_SQ_INSTS_VALU

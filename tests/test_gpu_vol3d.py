@@ -17,6 +17,12 @@ pytestmark = pytest.mark.gpu
     (2, 8, 6, 9, 9, 16, 3, 1, 1),
     (1, 16, 7, 10, 8, 32, 3, 2, 1),      # stride 2 in all three dims
     (2, 12, 5, 6, 6, 8, 1, 2, 0),        # 1x1x1 strided shortcut
+    # Ci % 16 == 0: the forward decodes the depth taps inside the gather (edrl_conv3d_ndhwc_fwd_f32, no unfolded copy)
+    (5, 16, 2, 4, 4, 16, 3, 1, 1),       # 32 rows per sample: a 128-row tile spans four samples (depth padding at every boundary)
+    (2, 64, 4, 12, 12, 128, 3, 1, 1),
+    (3, 32, 5, 6, 6, 64, 1, 2, 0),       # 1x1x1 stride-2 shortcut
+    (2, 32, 9, 7, 5, 48, 3, 2, 1),       # stride 2 in all three dims, odd sizes
+    (1, 128, 6, 14, 14, 256, 3, 1, 1),   # 128-wide N tiles
 ])
 def test_conv3d_fwd_dgrad_wgrad_vs_torch(edrl, dev, case):
     from edrl_amd_pkg.encoders3d import Conv3dFn
