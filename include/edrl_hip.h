@@ -80,6 +80,13 @@ int edrl_conv1x1_k64_bwd_bf16(const void* g, const void* yraw, const float* bcoe
                               const void* wt, void* g2, float* ep_part, size_t ep_part_bytes, float* dw, float* workspace,
                               size_t workspace_bytes, int N, int H, int W, int Ci, int Co, hipStream_t stream);
 
+/* Weight gradient of that stem on the bf16 matrix pipe: dy = d_raw of the stem's BatchNorm, bf16 [N,Hs,Ws,64]; xs as above; the image
+ * is rounded to bf16 in registers; dw fp32 [64][4][4][4] (folded layout; edrl_stem_weight_fold_f32 dir 1 gathers the 49 taps),
+ * ordered split reduction through `workspace` (edrl_stem_wgrad_s2d_bf16_workspace_bytes). */
+size_t edrl_stem_wgrad_s2d_bf16_workspace_bytes(int N, int Hs, int Ws);
+int edrl_stem_wgrad_s2d_bf16(const void* dy, const float* xs, float* dw, float* workspace, size_t workspace_bytes, int N, int Hs, int Ws,
+                             hipStream_t stream);
+
 /* Data gradient (autograd of the above): dx [+]= conv_transpose(dy, w).
  * wt is w permuted to [Ci,KH,KW,Co] by edrl_permute_weight_f32. */
 int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int Hi, int Wi, int Ci,

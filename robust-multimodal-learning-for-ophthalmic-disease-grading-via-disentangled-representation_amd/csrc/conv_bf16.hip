@@ -1187,6 +1187,20 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
   return 0;
 }
 
+// Weight gradient of the 1-channel stem on the bf16 matrix pipe: dy bf16 [N,Hs,Ws,64] (d_raw of the stem's BatchNorm), xs the fp32
+// space-to-depth image [N,Hs,Ws,4] -> dw fp32 [64][4][4][4] (the folded layout: edrl_stem_weight_fold_f32 dir 1 gathers the 7x7 taps).
+size_t edrl_stem_wgrad_s2d_bf16_workspace_bytes(int N, int Hs, int Ws) { return stem_wgrad_s2d_bf16_workspace_bytes(N, Hs, Ws); }
+int edrl_stem_wgrad_s2d_bf16(const void* dy, const float* xs, float* dw, float* workspace, size_t workspace_bytes, int N, int Hs, int Ws,
+                             hipStream_t st) {
+  if (!dy || !xs || !dw || !workspace || !stem_s2d_bf16_ok(N, Hs, Ws)) return EDRL_EINVAL;
+  if (workspace_bytes < stem_wgrad_s2d_bf16_workspace_bytes(N, Hs, Ws)) return EDRL_ENOSPC;
+  const int rc = launch_stem_wgrad_s2d_bf16(dy, xs, workspace, N, Hs, Ws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(edrl_cdiv(4096, 1024)), dim3(256), 0, st, workspace, dw, 4096L, stem_wgrad_s2d_bf16_splits(N, Hs, Ws), 0);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
 // Both gradients of an expanding 1x1 layer inside a fused-BatchNorm block in one pass over (g, yraw) (conv1x1_bwd_bf16.hip).
 int edrl_conv1x1_k64_bwd_ok_bf16(int N, int H, int W, int Ci, int Co) {
   return (edrl_cfg().bf16_k64_bwd != 0 && conv1x1_k64_bwd_ok(N, H, W, Ci, Co)) ? 1 : 0;

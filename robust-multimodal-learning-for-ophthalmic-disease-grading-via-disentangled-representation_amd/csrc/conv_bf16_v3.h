@@ -50,3 +50,8 @@ int launch_conv1x1_k64_bwd(const void* g, const void* yraw, const float* bcoef, 
 bool gather_bf16_v3p_ok(const GatherGeom& g, bool epi);
 int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st,
                            const GatherFuse* fuse = nullptr);
+
+// Weight gradient of the same stem (bf16 d_raw x fp32 space-to-depth image -> fp32 [64][4x4x4] slabs), conv_c64_bf16.hip.
+int stem_wgrad_s2d_bf16_splits(int N, int Hs, int Ws);
+size_t stem_wgrad_s2d_bf16_workspace_bytes(int N, int Hs, int Ws);
+int launch_stem_wgrad_s2d_bf16(const void* dy, const float* xs, float* slabs, int N, int Hs, int Ws, hipStream_t st);

@@ -252,11 +252,11 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
     const bool accum = g.flags & GF_ACCUM;
     // EPI 1 operands of this lane's 2 x 8 channels
     const __bf16* epx = reinterpret_cast<const __bf16*>(F.ep_x);
-    const bool use_mask = EPI != 0 && F.ep_mask != nullptr;
-    const bool use_relu = EPI != 0 && !use_mask && (g.flags & GF_EPI_RELU);
+    const bool use_mask = EPI == 1 && F.ep_mask != nullptr;
+    const bool use_relu = EPI == 1 && !use_mask && (g.flags & GF_EPI_RELU);
     const int nq = g.NC >> 2;
-    f32x4 s0[EPI ? 4 : 1], s1[EPI ? 4 : 1];        // [2 p + h]: sums of channels 32 p + cb0 + 4 h .. +3
-    if constexpr (EPI != 0) {
+    f32x4 s0[EPI == 1 ? 4 : 1], s1[EPI == 1 ? 4 : 1];        // [2 p + h]: sums of channels 32 p + cb0 + 4 h .. +3
+    if constexpr (EPI == 1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) s0[q] = s1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
     for (int p = 0; p < 2; ++p) {
       const int chan = en0 + wn0 + 32 * p + cb0;
       f32x4 mu0 = {0.f, 0.f, 0.f, 0.f}, mu1 = mu0, sc0 = mu0, sc1 = mu0, sh0 = mu0, sh1 = mu0;
-      if constexpr (EPI != 0) {
+      if constexpr (EPI == 1) {
         mu0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan); mu1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + chan + 4);
         if (use_relu) {
           sc0 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan); sc1 = *reinterpret_cast<const f32x4*>(F.ep_fcoef + 2 * (long)g.NC + chan + 4);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
           mb[q] = 0xffffu;
           if (pix >= 0) {
             if (accum) oldv[q] = *reinterpret_cast<const bf16x8*>(dst + pix * g.ld_dst + chan);
-            if constexpr (EPI != 0) {
+            if constexpr (EPI == 1) {
               xv[q] = *reinterpret_cast<const bf16x8*>(epx + pix * F.ld_ep + chan);
               if (use_mask) mb[q] = *reinterpret_cast<const unsigned short*>(F.ep_mask + pix * nq + (chan >> 2));
             }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v0[e] += (float)oldv[q][e]; v1[e] += (float)oldv[q][4 + e]; }
             }
-            if constexpr (EPI != 0) {
+            if constexpr (EPI == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float x0 = (float)xv[q][e], x1 = (float)xv[q][4 + e];
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
         }
       }
     }
-    if constexpr (EPI != 0) {
+    if constexpr (EPI == 1) {
       // sum over the 16 pixel lanes of this lane row (xor 1, 2, 4, 8 stay inside it); lane fr == 0 writes its 16 channels
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -359,6 +359,122 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
             *reinterpret_cast<f32x4*>(pp + chan) = s0[2 * p + h];
             *reinterpret_cast<f32x4*>(pp + g.NC + chan) = s1[2 * p + h];
           }
+      }
+    }
+  };
+
+  // ---- EPI 2: the BatchNorm-backward epilogue with LDS-staged rows.  The tile leaves the accumulators through the LDS image of the
+  // one-tile kernel (512-byte pixel rows), but every thread pulls its 16 row pieces into REGISTERS at once, which frees the ring for
+  // the next tile's first units before the global phase (raw tensor, accumulate target, sign bytes in, masked gradient out) starts.
+  bf16x8 ev[EPI == 2 ? 16 : 1];
+  auto stage_epi = [&]() {
+    if constexpr (EPI == 2) {
+      const int half8 = (fq & 1) * 8;
+      unsigned char* wr = smem + (wm0 + fr) * 512 + half8;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int slot = (((wn0 >> 3) + 2 * i + (fq >> 1)) ^ fr) << 4;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][e];
+          *reinterpret_cast<bf16x4*>(wr + j * 16 * 512 + slot) = o;
+        }
+      }
+      __syncthreads();
+      const int rr = tid >> 5, c = tid & 31;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) ev[it] = *reinterpret_cast<const bf16x8*>(smem + (it * 16 + rr) * 512 + ((c ^ rr) << 4));
+      __syncthreads();                              // image consumed: the ring may be refilled
+    }
+  };
+  auto finish_epi = [&](long em0, int en0) {
+    if constexpr (EPI == 2) {
+      const bool accum = g.flags & GF_ACCUM;
+      const int rr = tid >> 5, c = tid & 31;
+      const int n = en0 + c * 8;
+      const int nq = g.NC >> 2;
+      const __bf16* epx = reinterpret_cast<const __bf16*>(F.ep_x);
+      const bool use_mask = F.ep_mask != nullptr;
+      const bool use_relu = !use_mask && (g.flags & GF_EPI_RELU);
+      float em[8], esc[8], esh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        em[e] = F.ep_fcoef[n + e];
+        esc[e] = use_relu ? F.ep_fcoef[2 * (long)g.NC + n + e] : 0.f;
+        esh[e] = use_relu ? F.ep_fcoef[4 * (long)g.NC + n + e] : 0.f;
+      }
+      float s0[2][8], s1[2][8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[h][e] = s1[h][e] = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                 // chunk h of the tile = rows 128 h .. 128 h + 127
+        long pixs[8];
+        bf16x8 opre[8], xpre[8];
+        unsigned mb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {               // all global operands of the chunk requested up front
+          const long m = em0 + (h * 8 + i) * 16 + rr;
+          long pix = m;
+          if (g.step > 1 && m < g.M) {
+            const int nn = (int)(((unsigned long long)(unsigned)m * g.mg_ohw) >> g.sh_ohw);
+            const int rem = (int)m - nn * ohw;
+            const int ii = (int)(((unsigned long long)(unsigned)rem * g.mg_ow) >> g.sh_ow), jj = rem - ii * g.OWs;
+            pix = ((long)nn * g.OH + g.h0 + ii * g.step) * g.OW + g.w0 + jj * g.step;
+          }
+          pixs[i] = m < g.M ? pix : -1;
+          mb[i] = 0xffffu;
+          if (pixs[i] >= 0) {
+            xpre[i] = *reinterpret_cast<const bf16x8*>(epx + pix * F.ld_ep + n);
+            if (accum) opre[i] = *reinterpret_cast<const bf16x8*>(dst + pix * g.ld_dst + n);
+            if (use_mask) mb[i] = *reinterpret_cast<const unsigned short*>(F.ep_mask + pix * nq + (n >> 2));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (pixs[i] >= 0) {
+            const bf16x8 v = ev[EPI == 2 ? h * 8 + i : 0];
+            bf16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float vf = (float)v[e];
+              if (accum) vf += (float)opre[i][e];
+              const float xe = (float)xpre[i][e];
+              const bool keep = use_mask ? ((mb[i] >> ((e & 3) + 8 * (e >> 2))) & 1u) != 0u : (use_relu ? __builtin_fmaf(xe, esc[e], esh[e]) > 0.f : true);
+              vf = keep ? vf : 0.f;
+              s0[h][e] += vf;
+              s1[h][e] = __builtin_fmaf(vf, xe - em[e], s1[h][e]);
+              ov[e] = (__bf16)vf;
+            }
+            *reinterpret_cast<bf16x8*>(dst + pixs[i] * g.ld_dst + n) = ov;
+          }
+        }
+      }
+      // chunk sums across the 8 waves through ring slot 3 (free until the next tile's first K unit issues its pieces into it)
+      float* red = reinterpret_cast<float*>(smem + 3 * V3_UNIT);    // [chunk][plane][wave][256 channels] = 32 KiB
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[h][e] += __shfl_xor(s0[h][e], 32, 64); s1[h][e] += __shfl_xor(s1[h][e], 32, 64); }
+      if (lane < 32) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            red[((h * 2 + 0) * 8 + wave) * 256 + c * 8 + e] = s0[h][e];
+            red[((h * 2 + 1) * 8 + wave) * 256 + c * 8 + e] = s1[h][e];
+          }
+      }
+      __syncthreads();
+      for (int o = tid; o < 1024; o += 512) {       // ordered sum over the 8 waves: deterministic
+        const int h = o >> 9, pl = (o >> 8) & 1, ch = o & 255;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[((h * 2 + pl) * 8 + w) * 256 + ch];
+        if (em0 + h * 128 < g.M) F.ep_part[((long)F.ep_chunk0 + (em0 >> 7) + h) * 2 * g.NC + (long)pl * g.NC + en0 + ch] = t;
       }
     }
   };
@@ -391,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
     tk += wstride;
     const bool more = tk < tcount;
     __builtin_amdgcn_s_barrier();                              // every wave has read its last fragments: the ring is free
+    stage_epi();
     if (more) {
       setup(tbase + tk);
       if (KU > 0) {
@@ -399,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    epilogue(em0, en0);
+    if constexpr (EPI == 2) finish_epi(em0, en0); else epilogue(em0, en0);
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -408,10 +525,12 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_v3p_kernel(const __bf
   }
 }
 
-// EDRL_BF16_V3_PERSIST: 0 off, 1 (default) forward / plain data gradient, 2 also the data gradient with the BatchNorm-backward
-// epilogue.  Measured at C2 (6 steps, same box): mode 1 320.4 ms per step, mode 2 324.9 -- the register epilogue touches 64-byte
-// segments of 16 pixel rows per instruction on THREE streams there (raw tensor, accumulate target, result), the LDS-staged
-// epilogue of conv_bf16_v3.hip whole 512-byte rows; with one stream (plain stores) the overlap with the next tile's loads wins.
+// EDRL_BF16_V3_PERSIST: 0 off; 1 forward / plain data gradient only (the data gradient with the BatchNorm-backward epilogue stays on
+// the one-tile kernel); 2 also that data gradient, with LDS-staged rows pulled into registers before the next tile's loads (EPI 2);
+// 3 the same with the register-form epilogue (EPI 1).  Measured at C2 (6 steps, same box): mode 1 320.4 ms per step, mode 3 324.9 --
+// the register epilogue touches 64-byte segments of 16 pixel rows per instruction on THREE streams there (raw tensor, accumulate
+// target, result), the LDS-staged epilogue whole 512-byte rows; with one stream (plain stores) the overlap with the next tile's
+// loads wins.
 bool gather_bf16_v3p_ok(const GatherGeom& g, bool epi) {
   return edrl_cfg().bf16_v3_persist >= (epi ? 2 : 1) && g.M < 0x7fffffff;
 }
@@ -426,14 +545,21 @@ int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const Gat
   if (nt > 0x7fffffffL) return EDRL_EINVAL;
   if (((uintptr_t)src & 15) || ((uintptr_t)wm & 15) || ((uintptr_t)dst & 15)) return EDRL_EINVAL;
   int grid = nt >= 256 ? 256 : (int)((nt + 7) / 8 * 8);      // one workgroup per CU; a multiple of 8 (XCD-contiguous tile ranges)
-  static bool attr_set[3] = {false, false, false};
+  static bool attr_set[2] = {false, false};
   GatherFuse F;
   memset(&F, 0, sizeof(F));
   if (fuse && fuse->ep_x) {
     if (!dgrad) return EDRL_EINVAL;
-    auto kern = conv_gather_bf16_v3p_kernel<true, 1>;
-    if (!attr_set[2]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_set[2] = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt, *fuse);
+    static bool attr_e[2] = {false, false};
+    if (edrl_cfg().bf16_v3_persist == 3) {          // register form of the epilogue (A/B: loses, see gather_bf16_v3p_ok)
+      auto kern = conv_gather_bf16_v3p_kernel<true, 1>;
+      if (!attr_e[0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_e[0] = true; }
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt, *fuse);
+    } else {                                        // LDS-staged rows, pulled into registers before the next tile's loads are issued
+      auto kern = conv_gather_bf16_v3p_kernel<true, 2>;
+      if (!attr_e[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr_e[1] = true; }
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), V3_LDS, st, (const __bf16*)src, (const __bf16*)wm, (__bf16*)dst, g, tiles_n, (int)nt, *fuse);
+    }
     EDRL_LAUNCH_CHECK();
     return 0;
   }

@@ -567,6 +567,117 @@ int launch_stem_s2d_bf16(const float* xs, const void* w, void* y, int N, int Hs,
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 1-channel stem on the bf16 matrix pipe: dW [64 co][64 k] = sum_pixels d_raw[px][co] * patch[px][k], with
+// patch[px][k] the 4x4 window of the space-to-depth fp32 image (k = (window row, column, channel), the forward's K order) rounded to
+// bf16 in registers, d_raw bf16 [M][64].  3.3 GB of gradient + 0.4 GB of image per 2048 224x224 slices against 0.2 TFLOP: streaming.
+// 256 threads, 32 KiB of LDS: both 128-pixel tiles go to LDS as [pixel][64] images (16-byte chunks XOR-swizzled so that the
+// transposing fragment reads are conflict-free), each of the 4 waves owns one 32 x 32 block of dW (8 v_mfma_f32_32x32x16_bf16 per
+// tile), accumulators live in registers across the workgroup's tiles, one [64][64] fp32 slab per workgroup (ordered reduction).
+typedef short sw_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int sw_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ c64_bf16x8 sw_tr_frag(const unsigned char* img, int pix0, int col0, int lane) {
+  const int g16 = lane & 15, q = g16 >> 2, p4 = g16 & 3;
+  const int col = col0 + 4 * p4;
+  const int chunk = col >> 3, inner = (col & 7) * 2;
+  const int r0 = pix0 + q, r1 = r0 + 4;
+  const sw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) sw_s16x4*)(img + r0 * 128 + ((chunk ^ sw_swz(r0)) * 16) + inner));
+  const sw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) sw_s16x4*)(img + r1 * 128 + ((chunk ^ sw_swz(r1)) * 16) + inner));
+  union { struct { sw_s16x4 l, h; } s; c64_bf16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_s2d_bf16_kernel(const __bf16* __restrict__ dy, const float* __restrict__ xs,
+                                                                     float* __restrict__ slabs, int M, int ntiles, StemGeom sg) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * 128];
+  unsigned char* dimg = smem;                 // d_raw tile [128 px][64 co] bf16
+  unsigned char* pimg = smem + 128 * 128;     // patch tile [128 px][64 k] bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cob = wave >> 1, kb = wave & 1;   // this wave's 32 x 32 block of dW
+  const int lh = lane >> 5, li = lane & 31, cg = 16 * ((lane >> 4) & 1);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr unsigned OOBX = 0x80000000u;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    long rows = (long)M - m0; if (rows > 128) rows = 128;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (long)m0 * 64), 0, (int)(rows * 128), 0x00020000);
+    const unsigned r0u = (unsigned)(((unsigned long long)(unsigned)m0 * sg.mg_w) >> sg.sh_w);
+    const unsigned n0img = (unsigned)(((unsigned long long)r0u * sg.mg_h) >> sg.sh_h);
+    const long imgb = (long)sg.Hs * sg.Ws * 16;
+    long remb = (long)M * 16 - (long)n0img * imgb;
+    if (remb > 0x7fffffffL) remb = 0x7fffffffL;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + (long)n0img * sg.Hs * sg.Ws * 4), 0, (int)remb, 0x00020000);
+    // ---- the tile's pieces: 4 of d_raw (16 bytes) and 4 of the patch matrix (8 floats = half a window row) per thread
+    c64_bf16x8 dv[4];
+    f32x4 lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, px = id >> 3, ch = id & 7;
+      dv[i] = __builtin_bit_cast(c64_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rd, (px * 64 + ch * 8) * 2, 0, 0));   // rows >= M: zeros
+      const int m = m0 + px;
+      const unsigned r = (unsigned)(((unsigned long long)(unsigned)m * sg.mg_w) >> sg.sh_w);
+      const int ow = m - (int)r * sg.Ws;
+      const unsigned nimg = (unsigned)(((unsigned long long)r * sg.mg_h) >> sg.sh_h);
+      const int oh = (int)r - (int)nimg * sg.Hs;
+      const int ih = oh - 2 + (ch >> 1), iw = ow - 2 + 2 * (ch & 1);
+      const bool rowok = m < M && (unsigned)ih < (unsigned)sg.Hs;
+      const unsigned off = (unsigned)((((int)(nimg - n0img) * sg.Hs + ih) * sg.Ws + iw) * 16);
+      const unsigned o0 = (rowok && (unsigned)iw < (unsigned)sg.Ws) ? off : OOBX;
+      const unsigned o1 = (rowok && (unsigned)(iw + 1) < (unsigned)sg.Ws) ? off + 16u : OOBX;
+      lo[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o0, 0, 0));
+      hi[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o1, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, px = id >> 3, ch = id & 7;
+      const int slot = (ch ^ sw_swz(px)) * 16;
+      *reinterpret_cast<c64_bf16x8*>(dimg + px * 128 + slot) = dv[i];
+      c64_bf16x8 pv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pv[e] = (__bf16)lo[i][e]; pv[4 + e] = (__bf16)hi[i][e]; }
+      *reinterpret_cast<c64_bf16x8*>(pimg + px * 128 + slot) = pv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int pix0 = 16 * ks + 8 * lh;
+      const c64_bf16x8 af = sw_tr_frag(dimg, pix0, 32 * cob + cg, lane);
+      const c64_bf16x8 bf = sw_tr_frag(pimg, pix0, 32 * kb + cg, lane);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (long)blockIdx.x * 64 * 64;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) slab[(32 * cob + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * kb + li] = acc[r];
+}
+
+static int stem_wgrad_grid(long M) {
+  const long nt = (M + 127) / 128;
+  return (int)(nt < 1024 ? nt : 1024);
+}
+int stem_wgrad_s2d_bf16_splits(int N, int Hs, int Ws) { return stem_wgrad_grid((long)N * Hs * Ws); }
+size_t stem_wgrad_s2d_bf16_workspace_bytes(int N, int Hs, int Ws) { return (size_t)stem_wgrad_grid((long)N * Hs * Ws) * 64 * 64 * sizeof(float); }
+// dy bf16 [N,Hs,Ws,64], xs fp32 [N,Hs,Ws,4] -> slabs [splits][64][64] fp32 (the caller reduces them in order)
+int launch_stem_wgrad_s2d_bf16(const void* dy, const float* xs, float* slabs, int N, int Hs, int Ws, hipStream_t st) {
+  if (!stem_s2d_bf16_ok(N, Hs, Ws) || ((uintptr_t)dy & 15) || ((uintptr_t)xs & 15) || ((uintptr_t)slabs & 15)) return EDRL_EINVAL;
+  const long M = (long)N * Hs * Ws;
+  StemGeom sg;
+  sg.Hs = Hs; sg.Ws = Ws;
+  gather_magic((unsigned)Ws, &sg.mg_w, &sg.sh_w);
+  gather_magic((unsigned)Hs, &sg.mg_h, &sg.sh_h);
+  hipLaunchKernelGGL(stem_wgrad_s2d_bf16_kernel, dim3(stem_wgrad_grid(M)), dim3(256), 0, st, (const __bf16*)dy, xs, slabs, (int)M,
+                     (int)((M + 127) / 128), sg);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
 static int c64_ceil_log2(unsigned d) {
   int s = 0;
   while ((1u << s) < d) ++s;

@@ -5,6 +5,8 @@ current stream.  torch is used only for device memory (torch.empty from the cach
 views/concatenation and autograd bookkeeping.  There is no eager/CPU fallback: tensors that are
 not fp32 CUDA tensors are rejected.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -236,6 +238,9 @@ def stem_conv_fwd_obf16(x, w):
     return out, part, chunks, xin, folded
 
 
+_STEM_WGRAD_MMA = os.environ.get("EDRL_BF16_STEM_WGRAD_MMA", "1") != "0"     # 0: the fp32 weight-gradient kernel with bf16 dy widened on load
+
+
 def stem_conv_fwd_bf16mma(x, w):
     """The stem of the 1-channel bf16 trunk on the bf16 matrix pipe (edrl_stem_conv_s2d_bf16): x fp32 [N,H,W,1] with even H, W,
     w fp32 [64,7,7,1].  -> (y bf16 [N,H/2,W/2,64], part, chunks, space-to-depth image kept for the weight gradient, True)."""
@@ -254,6 +259,17 @@ def stem_conv_fwd_bf16mma(x, w):
 
 def stem_conv_wgrad(dy, x_saved, w_shape, folded):
     """dy fp32, or bf16 (the bf16 trunk's stem: fp32 x, dy widened on load)."""
+    Co, _, _, C = w_shape
+    if (folded and _STEM_WGRAD_MMA and dy.dtype == torch.bfloat16 and C == 1 and Co == 64 and x_saved.shape[-1] == 4
+            and tuple(w_shape[1:3]) == (7, 7)):
+        # 1-channel stem of the bf16 trunk: bf16 MFMA streaming kernel (image rounded to bf16 in registers)
+        N, Hs, Ws, _ = dy.shape
+        nbytes = L.query("edrl_stem_wgrad_s2d_bf16_workspace_bytes", N, Hs, Ws)
+        ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+        dw8 = torch.empty((64, 4, 4, 4), device=dy.device, dtype=torch.float32)
+        _launch_timed("conv_wgrad_bf16", 2.0 * N * Hs * Ws * 64 * 49, "edrl_stem_wgrad_s2d_bf16", P(dy), P(x_saved), P(dw8), P(ws), nbytes,
+                      N, Hs, Ws, kernels=2, nbytes=2.0 * dy.numel() + 4.0 * (x_saved.numel() + dw8.numel()))
+        return stem_weight_fold(dw8, inverse=True)
     if not folded:
         return conv2d_wgrad(dy, x_saved, tuple(w_shape), 2, 3)
     Co, _, _, C = w_shape

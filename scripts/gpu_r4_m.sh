@@ -1,0 +1,15 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_bf16.py -m gpu -q --timeout 600 -p no:cacheprovider -x -k "v3_epilogue" > gpurun_out/r4m_pytest.log 2>&1
+rc=$?; echo "pytest exit=$rc" >> gpurun_out/r4m_pytest.log; tail -3 gpurun_out/r4m_pytest.log
+[ $rc -eq 0 ] || exit $rc
+for v in 1 2 1 2; do
+  EDRL_BF16_V3_PERSIST=$v timeout -k 10 300 python bench.py --config C2 --steps 6 --warmup 2 --no-cpu-baseline --no-recompute-leg --no-overlap-leg > gpurun_out/r4m_c2.json 2>/dev/null
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/r4m_c2.json"))
+print("persist=$v value", d["value"], "ms", d["ms_per_step"], {k:round(x["ms_total"]/6,1) for k,x in d["kernels"].items() if "bf16" in k})
+PY
+done
+exit 0

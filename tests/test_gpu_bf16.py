@@ -725,7 +725,7 @@ V3_EPI_CASES = [
 ]
 
 
-@pytest.mark.parametrize("persist", ["1", "0"])
+@pytest.mark.parametrize("persist", ["2", "3", "0"])      # persistent with LDS-staged rows / persistent register form / one tile per workgroup
 @pytest.mark.parametrize("case", V3_EPI_CASES)
 def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, persist, switches):
     """The BatchNorm-backward epilogue of the 256x256 LDS-DMA data-gradient core (conv_bf16_v3.hip EPI 1: accumulate, mask with
@@ -757,7 +757,7 @@ def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, persi
     care = torch.ones_like(keep) if use_mask else (pre.abs() > 1e-6 * pre.abs().max())
     wt = ops.permute_weight_bf16(w.float().to(dev))
     outs = {}
-    switches(EDRL_BF16_V3_PERSIST=persist)      # "1": conv_bf16_v3p.hip (register epilogue, per-wave chunk sums), "0": conv_bf16_v3.hip
+    switches(EDRL_BF16_V3_PERSIST=persist)      # "2" / "3": conv_bf16_v3p.hip (EPI 2 / EPI 1), "0": conv_bf16_v3.hip
     for mode in ("0", "2"):
         switches(EDRL_BF16_V3=mode)
         dst = old.clone().to(dev) if accum else None
@@ -882,3 +882,33 @@ def test_conv1x1_k64_bwd_one_pass_kernel_vs_fp64_and_two_kernel_path(edrl, dev, 
     check("one-pass vs two-kernel dW", dw.cpu(), dw2.cpu(), 2e-5)
     e2 = ((g2.double() - g22.double()).cpu().reshape(-1, Ci) * care).abs().max() / g2_ref.abs().max()
     assert e2 <= BF16_TOL, f"one-pass vs two-kernel g2: {e2:.3e}"
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 32, 32), (2, 30, 34), (5, 8, 6), (2, 224, 224)])
+def test_stem_wgrad_bf16_mma_kernel_vs_fp64_and_fp32_kernel(edrl, dev, N, H, W, switches):
+    """Weight gradient of the 1-channel stem on the bf16 matrix pipe (edrl_stem_wgrad_s2d_bf16: d_raw bf16 x the space-to-depth fp32
+    image rounded to bf16 in registers, 128-pixel tiles through swizzled LDS images, transposing fragment reads, ordered slab
+    reduction).  Against the fp64 weight gradient of the 7x7/s2/p3 convolution on the SAME bf16-rounded image and gradient at 2e-5 of
+    its max (fp32 accumulation of bf16 products); against the fp32 kernel it replaces (unrounded image) within the operand rounding,
+    1e-2; bit-reproducible."""
+    import os
+    ops = edrl.ops
+    g = torch.Generator().manual_seed(N * 11 + W)
+    x = torch.rand(N, H, W, 1, generator=g)
+    dy = torch.randn(N, H // 2, W // 2, 64, generator=g).bfloat16()
+    wd = torch.zeros(64, 1, 7, 7, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2), wd, stride=2, padding=3).backward(nchw(dy.double()))
+    ref = wd.grad.permute(0, 2, 3, 1)                                   # [64,7,7,1]
+    xs = ops.space_to_depth2(x.to(dev))
+    dw = ops.stem_conv_wgrad(dy.to(dev), xs, (64, 7, 7, 1), True)
+    dw_b = ops.stem_conv_wgrad(dy.to(dev), xs, (64, 7, 7, 1), True)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw_b), "deterministic"
+    check(f"bf16-MMA stem wgrad {N}x{H}x{W}", dw.cpu(), ref, 2e-5)
+    old = ops._STEM_WGRAD_MMA
+    ops._STEM_WGRAD_MMA = False
+    try:
+        dw32 = ops.stem_conv_wgrad(dy.to(dev), xs, (64, 7, 7, 1), True)
+    finally:
+        ops._STEM_WGRAD_MMA = old
+    check(f"bf16-MMA stem wgrad vs fp32 kernel {N}x{H}x{W}", dw.cpu(), dw32.cpu(), 1e-2)
