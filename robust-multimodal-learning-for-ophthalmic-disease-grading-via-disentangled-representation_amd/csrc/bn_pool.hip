@@ -958,6 +958,50 @@ __device__ __forceinline__ void maxpool_bn_gather_g8(const __bf16* __restrict__ 
     for (int e = 0; e < 4; ++e) s[q][e] = pre[e] > 0.f ? s[q][e] : 0.f;
   }
 }
+// Branch-free form of the gather (round 4): the (up to) four windows that cover an input pixel are all requested at once through
+// buffer descriptors over dy / idx -- a window that does not exist for this pixel's parity (or lies past the edge) is an out-of-range
+// offset, which reads as zeros and an index byte that matches no tap.  The loop form above predicates each window's loads on the
+// pixel's parity: lanes of one wave differ in parity, so every wave ran all four iterations with one exposed latency each.
+__device__ __forceinline__ void maxpool_bn_gather_g8_buf(const __amdgpu_buffer_rsrc_t rdy, const __amdgpu_buffer_rsrc_t ridx,
+                                                         const f32x4 (&xr)[2], const f32x4 (&sc)[2], const f32x4 (&sh)[2], int n, int h,
+                                                         int w, int c, int C, int Ho, int Wo, f32x4 (&s)[2]) {
+  constexpr unsigned OOBP = 0x80000000u;
+  const int nh = (h & 1) ? 2 : 1, nw = (w & 1) ? 2 : 1;
+  const int ho0 = (h + 1) >> 1, wo0 = (w + 1) >> 1;
+  const int kh0 = (h & 1) ? 0 : 1, kw0 = (w & 1) ? 0 : 1;
+  bf16x8_t gv[4];
+  unsigned mx[4], my[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ho = ho0 - a, wo = wo0 - b;
+      const bool ok = a < nh && b < nw && ho < Ho && wo < Wo;
+      const unsigned o = (unsigned)(((n * Ho + ho) * Wo + wo) * C + c);      // (element offset < 2^30: host-checked)
+      const auto m2 = __builtin_amdgcn_raw_buffer_load_b64(ridx, ok ? (int)o : (int)OOBP, 0, 0);
+      mx[2 * a + b] = ok ? (unsigned)m2[0] : 0xffffffffu;
+      my[2 * a + b] = ok ? (unsigned)m2[1] : 0xffffffffu;
+      gv[2 * a + b] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? (int)(o * 2u) : (int)OOBP, 0, 0));
+    }
+  s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const unsigned tap = (unsigned)((kh0 + 2 * a) * 3 + kw0 + 2 * b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (((mx[2 * a + b] >> (8 * e)) & 0xff) == tap) s[0][e] += (float)gv[2 * a + b][e];
+        if (((my[2 * a + b] >> (8 * e)) & 0xff) == tap) s[1][e] += (float)gv[2 * a + b][4 + e];
+      }
+    }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const f32x4 pre = edrl_bn_pre2(xr[q], sc[q], sh[q]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[q][e] = pre[e] > 0.f ? s[q][e] : 0.f;
+  }
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void maxpool_bn_bwd8_kernel(const __bf16* __restrict__ dy, const unsigned char* __restrict__ idx,
                                                               const __bf16* __restrict__ x, const float* __restrict__ fcoef,
@@ -995,10 +1039,16 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd8_kernel(const __bf16* __re
     int w = (int)(r % W);
     const long t = r / W;
     int h = (int)(t % H), n = (int)(t / H);
+    // pooled tensors below 2^30 elements: the four windows of a pixel through descriptors (see maxpool_bn_gather_g8_buf)
+    const long pooled = (long)N * Ho * Wo * C;
+    const bool usebuf = pooled < (1L << 30);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, usebuf ? (int)(pooled * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc((void*)idx, 0, usebuf ? (int)pooled : 0, 0x00020000);
     for (; r < row1; r += RL) {
       f32x4 xr[2], g[2];
       ld8h(x + r * C + c, xr[0], xr[1]);
-      maxpool_bn_gather_g8(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo, g);
+      if (usebuf) maxpool_bn_gather_g8_buf(rdy, ridx, xr, sc, sh, n, h, w, c, C, Ho, Wo, g);
+      else maxpool_bn_gather_g8(dy, idx, xr, sc, sh, n, h, w, c, C, Ho, Wo, g);
       if (MODE == 1) {
         st8h(dx + r * C + c, edrl_bn_bwd_dx2(g[0], xr[0], p0[0], p1[0], p2[0]), edrl_bn_bwd_dx2(g[1], xr[1], p0[1], p1[1], p2[1]));
       } else {

@@ -12,6 +12,7 @@ static long env_long(const char* name, long dflt) { const char* e = getenv(name)
 static void load(EdrlConfig& c) {
   c.bf16_v3 = env_int("EDRL_BF16_V3", 1);
   c.bf16_v3_persist = env_int("EDRL_BF16_V3_PERSIST", 1);
+  c.v3_epi_kmin = env_int("EDRL_V3_EPI_KMIN", 512);
   c.v3_fwd_kmin = env_int("EDRL_V3_FWD_KMIN", 256);
   c.v3_stagger = env_int("EDRL_V3_STAGGER", 0);
   c.bf16_wgrad_v3 = env_int("EDRL_BF16_WGRAD_V3", 1);

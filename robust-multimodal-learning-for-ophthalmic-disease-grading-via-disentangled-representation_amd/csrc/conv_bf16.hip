@@ -1176,7 +1176,7 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
       if (g.Ktot == 0 && (flags & GF_ACCUM) && !ep_raw) continue;
       F.ep_chunk0 = chunk0;
       // wide layers with a materialised d_raw: the 256x256 LDS-DMA core with the masking + partial-sum epilogue
-      const bool v3e = plain_in && gather_bf16_v3_ok(g, true) && gather_bf16_v3_epi_ok(g, F);
+      const bool v3e = plain_in && gather_bf16_v3_ok(g, true) && gather_bf16_v3_epi_ok(g, F) && g.Ktot >= edrl_cfg().v3_epi_kmin;
       const int rc = v3e ? launch_gather_bf16_v3(g_in, wt, dx, g, true, st, &F)
                      : plain_in ? dispatch_gather_fused_bf16<true, 0, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)
                      : ep_raw ? dispatch_gather_fused_bf16<true, 2, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)

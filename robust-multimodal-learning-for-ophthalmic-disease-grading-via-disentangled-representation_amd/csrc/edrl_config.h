@@ -8,6 +8,7 @@ struct EdrlConfig {
   // bf16 trunk (C2/C4)
   int bf16_v3;           // EDRL_BF16_V3          0 off | 1 auto | 2 wherever the geometry allows: 256x256 LDS-DMA forward / data-gradient core
   int bf16_v3_persist;   // EDRL_BF16_V3_PERSIST 0: one tile per workgroup (round 3) | 1 (default): persistent forward / plain data gradient | 2: also the epilogue variant
+  int v3_epi_kmin;       // EDRL_V3_EPI_KMIN      the data gradient WITH the BatchNorm-backward epilogue takes the v3 core from K >= this (512: the K = 256 block-input gradients are all epilogue and run 1 ms per C2 step faster on three 128-row workgroups per CU)
   int v3_fwd_kmin;       // EDRL_V3_FWD_KMIN      the v3 forward takes K >= this (256 since the persistent form; 512 in round 3)
   int v3_stagger;        // EDRL_V3_STAGGER       1: staggered DMA issue of the two wave halves
   int bf16_wgrad_v3;     // EDRL_BF16_WGRAD_V3    0 | 1 | 2: 256x256 LDS-DMA weight-gradient core
