@@ -76,8 +76,8 @@ def test_encoders_tokens(edrl, dev):
     check("fundus_pooled", p.cpu(), pr, 1e-4)
 
 
-@pytest.mark.parametrize("depth,in_ch", [(50, 3), (18, 1)])
-def test_trunk_recompute_block_outputs_bit_identical(edrl, dev, depth, in_ch):
+@pytest.mark.parametrize("depth,in_ch,dtype", [(50, 3, "fp32"), (18, 1, "fp32"), (50, 1, "bf16")])
+def test_trunk_recompute_block_outputs_bit_identical(edrl, dev, depth, in_ch, dtype):
     """args.activation_recompute (ResNetTrunk.recompute_out, the mode BASELINE.json's B=64/GPU fp32 shapes need): the block
     outputs rebuilt in backward come from the forward's own kernel on the same operands, so features, every parameter gradient
     and the running statistics must be bit-identical to the run that kept them."""
@@ -89,7 +89,7 @@ def test_trunk_recompute_block_outputs_bit_identical(edrl, dev, depth, in_ch):
     res = []
     for rec in (False, True):
         torch.manual_seed(0)
-        trunk = edrl.ResNetTrunk(depth, in_ch).to(dev).train()
+        trunk = edrl.ResNetTrunk(depth, in_ch, dtype=dtype).to(dev).train()      # bf16: fused stage-1/2 blocks + the wide blocks of stages 3-4
         trunk.recompute_out = rec
         f = trunk(x.to(dev))
         if gy is None:
