@@ -25,6 +25,9 @@ import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC is the only mode this host driver supports (RCCL / cross-process device memory); it has to be in the environment
+# before the HSA runtime starts, i.e. before the first torch.cuda call, not only before init_process_group
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 CONFIGS = {
     # name: (per-GPU batch, encoder depth, H=W, slices, encoder dtype, description)
