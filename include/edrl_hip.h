@@ -435,6 +435,18 @@ int edrl_conv3d_fwd_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho
 int edrl_conv3d_ndhwc_fwd_f32(const float* x, const float* w, float* y, int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo,
                               int Co, int KD, int KH, int KW, int dstride, int stride, int dpad, int pad, hipStream_t stream);
 
+/* 3-D convolution data gradient over NDHWC volumes without the k_d-times unfolded gradient and its fold pass (same row of SURVEY.md
+ * section 8f; the gradient of the layers above, baseline_models.py:154-178): dy [N,Do,Ho,Wo,Co] -> dx [N,Di,Hi,Wi,Ci].  `wt3` is
+ * the class-wise permutation of the forward weight made by edrl_conv3d_dgrad_weight_f32 (Co*KH*KW*KD*Ci floats: per depth tap class
+ * kd % dstride the matrix [Ci][KH][KW][taps of the class, reversed][Co]).  Co % 16 == 0, Ci % 4 == 0, Di % dstride == 0,
+ * dstride == 1 or dstride == stride, power-of-two stride, 16-byte aligned tensors: edrl_conv3d_dgrad_ok_f32; callers fall back to
+ * edrl_conv2d_nhwc_dgrad_f32 on the unfolded form + edrl_depth_fold_f32 otherwise. */
+int edrl_conv3d_dgrad_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW,
+                             int dstride, int stride);
+int edrl_conv3d_dgrad_weight_f32(const float* w, float* wt3, int Co, int KH, int KW, int KD, int Ci, int dstride, hipStream_t stream);
+int edrl_conv3d_ndhwc_dgrad_f32(const float* dy, const float* wt3, float* dx, int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho,
+                                int Wo, int Co, int KD, int KH, int KW, int dstride, int stride, int dpad, int pad, hipStream_t stream);
+
 /* Run-time switches (EDRL_* environment variables, csrc/edrl_config.h) are read ONCE at first use; this re-reads them.  For tests
  * and A/B scripts, between launches (not while other threads launch).  Returns 1 if the library was built with -DEDRL_DIAG
  * (diagnostic kernel variants present: libedrl_hip_diag.so), 0 for the shipped library. */

@@ -288,7 +288,9 @@ __device__ __forceinline__ u32x2 edrl_pack_bf16x4(f32x4 v) {
 // OUT16 (forward, EPI 0, vector epilogue, no accumulate / multiplier): `dst` is a bf16 tensor -- the fp32 result is rounded once
 // on the way out (BatchNorm partials still come from the fp32 accumulators).  The bf16 trunk's stem: fp32 image in, fp32 MFMA,
 // bf16 raw tensor out like every other layer of that trunk.
-// VOL (forward, BUF, ATR 0, EPI 0, MASK): 3-D convolution -- a third tap level (depth) in the row / tap decode, see GatherGeom.
+// VOL (BUF, ATR 0, EPI 0, MASK): 3-D convolution -- a third tap level (depth) in the row / tap decode, see GatherGeom.  The data
+// gradient reaches it through edrl_conv3d_ndhwc_dgrad_f32, which hands every depth parity class to the kernel as a stride-1 depth
+// geometry over a depth-reversed, class-compacted weight matrix (no kernel code of its own).
 template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
           bool OUT16 = false, bool VOL = false>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherFuse F) {
   static_assert(ATR == 0 || BUF, "operand transforms ride on the buffer-descriptor path");
   static_assert(!OUT16 || (EPI == 0 && !DGRAD), "bf16 output: plain forward only");
-  static_assert(!VOL || (BUF && FAST && !DGRAD && ATR == 0 && EPI == 0 && MASK), "depth taps: plain forward on the descriptor path");
+  static_assert(!VOL || (BUF && FAST && ATR == 0 && EPI == 0 && MASK), "depth taps: plain forward / data gradient on the descriptor path");
   constexpr unsigned EB = OUT16 ? 2u : 4u;     // bytes per destination element
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -1758,6 +1760,97 @@ int edrl_conv2d_nhwc_dgrad_f32(const float* dy, const float* wt, float* dx, int 
       const int rc = dispatch_gather<true>(dy, wt, dx, nullptr, nullptr, g, st);
       if (rc) return rc;
     }
+  return 0;
+}
+
+// 3-D convolution data gradient over NDHWC volumes without the depth-unfolded gradient and its fold pass (SURVEY.md section 8f
+// row 4): dx[n,d,h,w,ci] = sum dy[n,(d+dpad-kd)/ds,(h+pad-kh)/s,(w+pad-kw)/s,co] * w[co,kh,kw,kd,ci] over the taps that divide.
+// Depth parity classes (d % dstride) are separate launches like the (h, w) classes of the 2-D data gradient; inside a class the
+// source depth is dd + e0 - t for tap kd = q + t*dstride, which is the forward kernel's "rd + tap" with the taps REVERSED -- so
+// `wt3` holds, per tap class q = kd % dstride, the matrix [Ci][KH][KW][KDs_q reversed][Co] (edrl_conv3d_dgrad_weight_f32: classes
+// concatenated, KD*KH*KW*Ci*Co floats in all) and the kernel runs with depth stride 1.  The destination images of a class are
+// dpar + dd*dstride: with Di % dstride == 0 that is "image (n*Dc + dd) of a dstride-times taller tensor", i.e. the strided
+// epilogue's n*OH term with OH = Hi*dstride and the base moved by dpar images (needs dstride == 1 or dstride == stride).
+int edrl_conv3d_dgrad_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW,
+                             int dstride, int stride) {
+  if (N <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || KD <= 0 || KH <= 0 || KW <= 0) return 0;
+  if ((Co % 16) || (Ci % 4) || Ci <= 0 || Co <= 0 || dstride <= 0 || stride <= 0) return 0;
+  if (!(dstride == 1 || dstride == stride) || (stride & (stride - 1)) || (Di % dstride)) return 0;
+  if ((long)N * Di * Hi * Wi > 0x7fffffffL) return 0;
+  const long cvol = (long)(Di / dstride) * ((Hi + stride - 1) / stride) * ((Wi + stride - 1) / stride);   // rows of one sample in a class (upper bound)
+  const long ktot = (long)KD * KH * KW * Co;
+  if ((128 / (cvol > 0 ? cvol : 1) + 2) * (long)Do * Ho * Wo * Co * 4 >= (1L << 31) || (long)Ci * ktot * 4 >= (1L << 31)) return 0;
+  return 1;
+}
+
+__global__ void conv3d_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int T, int KD, int C,
+                                           int dstride) {
+  // w [Co][T = KH*KW][KD][C] -> per tap class q: wt_q [C][T][KDs_q][Co], entry t' = tap kd = q + (KDs_q - 1 - t') * dstride
+  const long n = (long)Co * T * KD * C;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  long r = i / C;
+  const int kd = (int)(r % KD); r /= KD;
+  const int t = (int)(r % T);
+  const int co = (int)(r / T);
+  const int q = kd % dstride, tt = kd / dstride;
+  long base = 0;                                   // classes 0 .. q-1 come first
+  for (int qq = 0; qq < q; ++qq) base += (long)C * T * ((KD - qq + dstride - 1) / dstride) * Co;
+  const int kds = (KD - q + dstride - 1) / dstride;
+  wt[base + (((long)c * T + t) * kds + (kds - 1 - tt)) * Co + co] = w[i];
+}
+
+int edrl_conv3d_dgrad_weight_f32(const float* w, float* wt3, int Co, int KH, int KW, int KD, int Ci, int dstride, hipStream_t st) {
+  if (!w || !wt3 || Co <= 0 || KH <= 0 || KW <= 0 || KD <= 0 || Ci <= 0 || dstride <= 0) return EDRL_EINVAL;
+  const long n = (long)Co * KH * KW * KD * Ci;
+  if (n > 0x7fffffffL) return EDRL_EINVAL;
+  hipLaunchKernelGGL(conv3d_dgrad_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt3, Co, KH * KW, KD, Ci, dstride);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
+int edrl_conv3d_ndhwc_dgrad_f32(const float* dy, const float* wt3, float* dx, int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho,
+                                int Wo, int Co, int KD, int KH, int KW, int dstride, int stride, int dpad, int pad, hipStream_t st) {
+  if (!dy || !wt3 || !dx || dpad < 0 || pad < 0) return EDRL_EINVAL;
+  if (!edrl_conv3d_dgrad_ok_f32(N, Di, Hi, Wi, Ci, Do, Ho, Wo, Co, KD, KH, KW, dstride, stride)) return EDRL_EINVAL;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)wt3 & 15) || ((uintptr_t)dx & 15)) return EDRL_EINVAL;
+  int sshift = 0;
+  while ((1 << sshift) < stride) ++sshift;
+  GatherGeom g;
+  g.OH = Hi * dstride; g.OW = Wi; g.NC = Ci; g.SH = Ho; g.SW = Wo; g.SC = Co;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+  g.ld_src = Co; g.ld_dst = Ci; g.ld_aux = 0; g.flags = GF_VEC_EPI;
+  g.step = stride; g.kstep = stride; g.sshift = sshift;
+  g.stat_part = nullptr; g.stat_shift = nullptr;
+  const int Dc = Di / dstride;
+  for (int dpar = 0; dpar < dstride; ++dpar) {
+    const int q = (dpar + dpad) % dstride;                       // tap class that reaches these depths
+    const int KDs = q < KD ? (KD - q + dstride - 1) / dstride : 0;
+    const int e0 = (dpar + dpad - q) / dstride;
+    long wbase = 0;
+    for (int qq = 0; qq < q; ++qq) wbase += (long)Ci * KH * KW * ((KD - qq + dstride - 1) / dstride) * Co;
+    g.KD = KDs; g.SD = Do; g.OD = Dc; g.dstride = 1; g.dpad = KDs - 1 - e0;
+    g.Kfull = KH * KW * KDs * Co;
+    float* dxc = dx + (long)dpar * Hi * Wi * Ci;
+    for (int ph = 0; ph < stride; ++ph)
+      for (int pw = 0; pw < stride; ++pw) {
+        g.h0 = ((ph - pad) % stride + stride) % stride;
+        g.w0 = ((pw - pad) % stride + stride) % stride;
+        g.OHs = g.h0 < Hi ? (Hi - g.h0 + stride - 1) / stride : 0;
+        g.OWs = g.w0 < Wi ? (Wi - g.w0 + stride - 1) / stride : 0;
+        if (g.OHs == 0 || g.OWs == 0) continue;
+        g.kh0 = ph; g.kw0 = pw;
+        g.KHs = (ph < KH && KDs > 0) ? (KH - ph + stride - 1) / stride : 0;
+        g.KWs = pw < KW ? (KW - pw + stride - 1) / stride : 0;
+        g.Ktot = g.KHs * g.KWs * KDs * Co;
+        g.M = (int)((long)N * Dc * g.OHs * g.OWs);
+        const bool narrow = Ci <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(Ci, 128) < edrl_cfg().narrow_below);
+        const int rc = narrow ? launch_gather_v2<128, 64, true, 16, 4, true, true, 0, 0, true, false, true>(dy, wt3 + wbase, dxc, nullptr, nullptr, g, st)
+                              : launch_gather_v2<128, 128, true, 16, 4, true, true, 0, 0, true, false, true>(dy, wt3 + wbase, dxc, nullptr, nullptr, g, st);
+        if (rc) return rc;
+      }
+  }
   return 0;
 }
 

@@ -72,8 +72,20 @@ class Conv3dFn(torch.autograd.Function):
         dw = ops.conv2d_wgrad(dy4, xu4, tuple(w.shape), s, p) if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dxu = ops.conv2d_dgrad(dy4, ops.permute_weight(w), tuple(xu4.shape), s, p)
-            dx = depth_fold(dxu.view(N, Do, H, W, CK), x_shape, KD, sd, pd)
+            Nn, D, _, _, C = x_shape
+            Co, KH, KW = w.shape[0], w.shape[1], w.shape[2]
+            Ho, Wo = dy4.shape[1], dy4.shape[2]
+            if CK == KD * C and L.query("edrl_conv3d_dgrad_ok_f32", Nn, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s):
+                # depth taps decoded inside the gather: the k_d x wide unfolded gradient and its fold pass do not exist
+                wt3 = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+                L.call("edrl_conv3d_dgrad_weight_f32", P(w), P(wt3), Co, KH, KW, KD, C, sd)
+                dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+                ops._launch_timed("conv_gather", 2.0 * dy4.numel() * KH * KW * KD * C, "edrl_conv3d_ndhwc_dgrad_f32", P(dy4), P(wt3),
+                                  P(dx), Nn, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s, pd, p,
+                                  kernels=sd * s * s, nbytes=4.0 * (dy4.numel() + w.numel() + dx.numel()))
+            else:
+                dxu = ops.conv2d_dgrad(dy4, ops.permute_weight(w), tuple(xu4.shape), s, p)
+                dx = depth_fold(dxu.view(N, Do, H, W, CK), x_shape, KD, sd, pd)
         return dx, dw, None, None, None, None, None
 
 

@@ -23,6 +23,12 @@ pytestmark = pytest.mark.gpu
     (3, 32, 5, 6, 6, 64, 1, 2, 0),       # 1x1x1 stride-2 shortcut
     (2, 32, 9, 7, 5, 48, 3, 2, 1),       # stride 2 in all three dims, odd sizes
     (1, 128, 6, 14, 14, 256, 3, 1, 1),   # 128-wide N tiles
+    # even depth: the data gradient decodes the depth taps in the gather as well (edrl_conv3d_ndhwc_dgrad_f32; depth parity classes)
+    (2, 32, 8, 7, 5, 48, 3, 2, 1),       # stride 2 in all three dims, odd in-plane sizes
+    (3, 32, 6, 6, 6, 64, 1, 2, 0),       # 1x1x1 stride-2 shortcut: the odd-depth class has no taps (zeros)
+    (2, 64, 4, 8, 8, 128, 3, 2, 1),
+    (2, 16, 2, 5, 5, 32, 3, 2, 1),       # one output depth
+    (1, 64, 4, 6, 6, 144, 3, 1, 1),      # Co = 144: a K tail inside the last tap
 ])
 def test_conv3d_fwd_dgrad_wgrad_vs_torch(edrl, dev, case):
     from edrl_amd_pkg.encoders3d import Conv3dFn
