@@ -447,6 +447,15 @@ int edrl_conv3d_dgrad_weight_f32(const float* w, float* wt3, int Co, int KH, int
 int edrl_conv3d_ndhwc_dgrad_f32(const float* dy, const float* wt3, float* dx, int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho,
                                 int Wo, int Co, int KD, int KH, int KW, int dstride, int stride, int dpad, int pad, hipStream_t stream);
 
+/* 3-D convolution weight gradient over NDHWC volumes without the depth-unfolded operand (same row): dy [N,Do,Ho,Wo,Co],
+ * x [N,Di,Hi,Wi,Ci] -> dw [Co,KH,KW,KD*Ci] (the depth-unfolded weight layout).  Workspace =
+ * edrl_conv2d_nhwc_wgrad_workspace_bytes(N*Do, Ho, Wo, Co, KD*Ci, KH, KW).  Ci % 4 == 0, Co % 4 == 0, dense 16-byte aligned tensors,
+ * buffer-load path geometry: edrl_conv3d_wgrad_ok_f32; callers fall back to edrl_depth_unfold_f32 + edrl_conv2d_nhwc_wgrad_f32. */
+int edrl_conv3d_wgrad_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW);
+int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int N, int Di,
+                                int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW, int dstride,
+                                int stride, int dpad, int pad, int accumulate, hipStream_t stream);
+
 /* Run-time switches (EDRL_* environment variables, csrc/edrl_config.h) are read ONCE at first use; this re-reads them.  For tests
  * and A/B scripts, between launches (not while other threads launch).  Returns 1 if the library was built with -DEDRL_DIAG
  * (diagnostic kernel variants present: libedrl_hip_diag.so), 0 for the shipped library. */

@@ -1161,6 +1161,10 @@ struct WgradGeom {
   long ld_dy, ld_x;
   int tiles_per_split;
   int tiles_x, tiles_y;   // dW tiles along K and Co: the grid is 1-D (tiles_x * tiles_y * splits), XCD-remapped
+  // Depth taps (VOL instantiations only: 3-D convolution over NDHWC volumes, edrl_conv3d_ndhwc_wgrad_f32): the pixel index
+  // enumerates (sample, do, oh, ow), the columns of dW run over (kh, kw, kd, ci) -- the weight layout of the depth-unfolded form --
+  // and the im2col operand is read from the volume itself, source image sample*SD + do*dstride - dpad + kd.
+  int KD, SD, OD, dstride, dpad;
 };
 
 // FASTLD (host-checked: VEC, 16/OW + 1 <= OH, per-block operand footprints < 2 GiB): both operands are fetched with
@@ -1180,11 +1184,14 @@ struct WgradFuse {
 // MASKX (XT 1): the conv has padding taps, which must read as exactly 0 after the transform (3x3); a 1x1 / pad-0 layer's only
 // invalid X rows are those past the end of the tensor, and they meet dY rows that DYT has already zeroed.
 // DY16 (FASTLD, no transforms): `dy` is a bf16 tensor, widened exactly on load (the stem of the bf16 trunk: its d_raw is stored as bf16).
+// VOL (FASTLD, no transforms): depth taps, see WgradGeom -- the thread's pixel-row state gains a third level (the source depth of
+// tap 0 and its wrap at a sample boundary), the depth tap of a column is a per-thread constant like its (kh, kw).
 template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true,
-          bool DY16 = false>
+          bool DY16 = false, bool VOL = false>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g, WgradFuse F) {
   static_assert((DYT == 0 && XT == 0) || FASTLD, "operand transforms ride on the buffer-descriptor path");
+  static_assert(!VOL || (FASTLD && DYT == 0 && XT == 0 && !DY16), "depth taps: plain buffer-load path only");
   static_assert(!DY16 || (FASTLD && DYT == 0), "bf16 dY: plain buffer-load path only");
   constexpr unsigned EBY = DY16 ? 2u : 4u;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -1246,6 +1253,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   unsigned a_off[A_LD], b_roff = 0;
   int b_ih = 0, b_iw = 0;                       // oh*stride - pad, ow*stride - pad of the thread's pixel row
   int f_kh[B_LD], f_kw[B_LD], f_tapc[B_LD];     // tap of load i and its byte offset (incl. channel) relative to (b_ih, b_iw)
+  int f_kd[VOL ? B_LD : 1];                     // VOL: depth tap of load i
+  int b_id = 0, id_lim = 0, v_ods = 0, v_dstr = 0;   // VOL: do*dstride - dpad of the thread's pixel row, its wrap limit / amounts
+  unsigned v_wrapd = 0;
   bool f_kval[B_LD];
   int ih_lim = 0, iw_lim = 0;
   unsigned a_step = 0, c_step = 0, c_wrapw = 0, c_wraph = 0;
@@ -1273,7 +1283,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
         q2 = *reinterpret_cast<const f32x4*>(F.bcoef + 2 * g.Co + co);
       }
     }
-    const long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
+    long n_lo = p_lo / ohw, n_hi = (p_hi - 1) / ohw;
+    if constexpr (VOL) { n_lo = n_lo / g.OD * g.SD; n_hi = n_hi / g.OD * g.SD + g.SD - 1; }   // whole volumes of the samples touched
     const long imgs = n_hi - n_lo + 1;
     const unsigned x_bytes = (unsigned)((imgs * g.SH * g.SW - 1) * ld4x + (unsigned)g.SC * 4u);
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + n_lo * g.SH * g.SW * g.ld_x), 0, (int)x_bytes, 0x00020000);
@@ -1287,6 +1298,11 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     c_step = (unsigned)(b16 * g.stride + a16 * g.stride * g.SW) * ld4x;
     c_wrapw = (unsigned)(g.stride * g.SW - g.OW * g.stride) * ld4x;
     c_wraph = (unsigned)(g.SH * g.SW - g.OH * g.stride * g.SW) * ld4x;
+    if constexpr (VOL) {      // the next (sample, do) is dstride source images further; past the last do: the next sample's volume
+      c_wraph += (unsigned)((g.dstride - 1) * g.SH * g.SW) * ld4x;
+      v_wrapd = (unsigned)((g.SD - g.OD * g.dstride) * g.SH * g.SW) * ld4x;
+      id_lim = g.OD * g.dstride - g.dpad; v_ods = g.OD * g.dstride; v_dstr = g.dstride;
+    }
     dw_step = b16 * g.stride; dh_step = a16 * g.stride;
     ih_lim = g.OH * g.stride - g.pad;
     iw_lim = g.OW * g.stride - g.pad;
@@ -1297,7 +1313,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
       const int oh = rem / g.OW, ow = rem - oh * g.OW;
       b_ih = oh * g.stride - g.pad;
       b_iw = ow * g.stride - g.pad;
-      b_roff = (unsigned)((((int)(n - n_lo) * g.SH + oh * g.stride) * g.SW + ow * g.stride) * (long)ld4x);
+      long img = n - n_lo;
+      if constexpr (VOL) {
+        const long smp = n / g.OD;
+        const int od = (int)(n - smp * g.OD);
+        b_id = od * g.dstride - g.dpad;
+        img = smp * g.SD + od * g.dstride - n_lo;
+      }
+      b_roff = (unsigned)((((int)img * g.SH + oh * g.stride) * g.SW + ow * g.stride) * (long)ld4x);
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -1305,8 +1328,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
       f_kval[i] = kcol_i < g.Ktot;
       int tap = 0, kc_i = 0;
       if (f_kval[i]) { tap = kcol_i / g.SC; kc_i = kcol_i - tap * g.SC; }
+      if constexpr (VOL) { f_kd[i] = tap % g.KD; tap /= g.KD; }
       f_kh[i] = tap / g.KW; f_kw[i] = tap - f_kh[i] * g.KW;
       f_tapc[i] = ((f_kh[i] - g.pad) * g.SW + (f_kw[i] - g.pad)) * (int)ld4x + kc_i * 4;
+      if constexpr (VOL) f_tapc[i] += (f_kd[i] - g.dpad) * g.SH * g.SW * (int)ld4x;
       if constexpr (XT == 1) {
         xs[i] = xb[i] = q0;
         if (f_kval[i]) {
@@ -1338,7 +1363,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      const bool ok = f_kval[i] && (unsigned)(b_ih + f_kh[i]) < (unsigned)g.SH && (unsigned)(b_iw + f_kw[i]) < (unsigned)g.SW;
+      bool ok = f_kval[i] && (unsigned)(b_ih + f_kh[i]) < (unsigned)g.SH && (unsigned)(b_iw + f_kw[i]) < (unsigned)g.SW;
+      if constexpr (VOL) ok = ok && (unsigned)(b_id + f_kd[VOL ? i : 0]) < (unsigned)g.SD;
       const unsigned off = ok ? b_roff + (unsigned)f_tapc[i] : OOB;
       b_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
       if constexpr (XT == 1 && MASKX) b_ok[i] = off <= x_last;
@@ -1348,6 +1374,11 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     b_iw -= w ? v_ows : 0; b_ih += w ? v_str : 0; b_roff += w ? v_wrapw : 0u;
     const bool h = b_ih >= ih_lim;
     b_ih -= h ? v_ohs : 0; b_roff += h ? v_wraph : 0u;
+    if constexpr (VOL) {
+      b_id += h ? v_dstr : 0;
+      const bool d = b_id >= id_lim;
+      b_id -= d ? v_ods : 0; b_roff += d ? v_wrapd : 0u;
+    }
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_tile_vec = [&]() {   // loads the tile the running state points at, then advances the state by one tile
@@ -1559,11 +1590,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #define WG_BK 16
 #define WG_OCC 4
 #define WG_OCC_FUSED 3
-template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true, bool DY16 = false>
+template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true, bool DY16 = false,
+          bool VOL = false>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st, const WgradFuse* fuse = nullptr) {
   const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (XT ? WG_OCC_FUSED : WG_OCC), FASTLD, DYT, XT, MASKX, DY16>;
+  auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (XT ? WG_OCC_FUSED : WG_OCC), FASTLD, DYT, XT, MASKX, DY16, VOL>;
   WgradFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
   static bool attr_set = false;
@@ -1945,6 +1977,51 @@ int edrl_conv2d_nhwc_wgrad_f32(const float* dy, const float* x, float* dw, float
                                int accumulate, hipStream_t st) {
   return wgrad_impl(dy, x, dw, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, ld_dy, ld_x,
                     accumulate, nullptr, st);
+}
+
+// 3-D convolution weight gradient over NDHWC volumes without the depth-unfolded operand:
+// dw[co,kh,kw,kd*Ci+ci] = sum dy[n,do,ho,wo,co] * x[n,do*ds-dpad+kd,ho*s-pad+kh,wo*s-pad+kw,ci] -- the weight layout of the
+// depth-unfolded form.  Workspace: edrl_conv2d_nhwc_wgrad_workspace_bytes(N*Do, Ho, Wo, Co, KD*Ci, KH, KW) (the same split-K plan).
+// Ci % 4 == 0, Co % 4 == 0, 16-byte aligned dense tensors, buffer-load path geometry: edrl_conv3d_wgrad_ok_f32.
+int edrl_conv3d_wgrad_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW) {
+  if (N <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || KD <= 0 || KH <= 0 || KW <= 0)
+    return 0;
+  if ((Ci % 4) || (Co % 4)) return 0;
+  const long P = (long)N * Do * Ho * Wo;
+  if (P > 0x7fffffffL || (long)KD * KH * KW * Ci > 0x7fffffffL) return 0;
+  int bm, bn, splits, tps;
+  wgrad_plan(P, Co, KD * KH * KW * Ci, KD * KH * KW, &bm, &bn, &splits, &tps);
+  const long span = (long)tps * WG_BK;
+  return (WG_BK / Wo + 1 <= Ho) && span * Co * 4 < (1L << 31) &&
+         (span / ((long)Do * Ho * Wo) + 2) * Di * Hi * Wi * Ci * 4 < (1L << 31);
+}
+int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int N, int Di,
+                                int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW, int dstride,
+                                int stride, int dpad, int pad, int accumulate, hipStream_t st) {
+  if (!dy || !x || !dw || dstride <= 0 || stride <= 0 || dpad < 0 || pad < 0) return EDRL_EINVAL;
+  if (!edrl_conv3d_wgrad_ok_f32(N, Di, Hi, Wi, Ci, Do, Ho, Wo, Co, KD, KH, KW)) return EDRL_EINVAL;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15)) return EDRL_EINVAL;
+  if ((long)(Ho - 1) * stride - pad + KH - 1 > (long)Hi - 1 + pad || (long)(Do - 1) * dstride - dpad + KD - 1 > (long)Di - 1 + dpad)
+    return EDRL_EINVAL;
+  WgradGeom g;
+  g.P = (long)N * Do * Ho * Wo;
+  g.OH = Ho; g.OW = Wo; g.Co = Co; g.SH = Hi; g.SW = Wi; g.SC = Ci;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KD * KH * KW * Ci;
+  g.ld_dy = Co; g.ld_x = Ci;
+  g.KD = KD; g.SD = Di; g.OD = Do; g.dstride = dstride; g.dpad = dpad;
+  int bm, bn, splits;
+  wgrad_plan(g.P, Co, g.Ktot, KD * KH * KW, &bm, &bn, &splits, &g.tiles_per_split);
+  if (workspace_bytes < (size_t)splits * Co * g.Ktot * sizeof(float) || workspace == nullptr) return EDRL_ENOSPC;
+  int rc;
+  if (bm == 64 && bn == 64) rc = launch_wgrad<64, 64, true, true, 0, 0, true, false, true>(dy, x, workspace, g, splits, st);
+  else if (bm == 64) rc = launch_wgrad<64, 128, true, true, 0, 0, true, false, true>(dy, x, workspace, g, splits, st);
+  else if (bn == 64) rc = launch_wgrad<128, 64, true, true, 0, 0, true, false, true>(dy, x, workspace, g, splits, st);
+  else rc = launch_wgrad<128, 128, true, true, 0, 0, true, false, true>(dy, x, workspace, g, splits, st);
+  if (rc) return rc;
+  const long n = (long)Co * g.Ktot;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(edrl_cdiv(n, 1024)), dim3(256), 0, st, workspace, dw, n, splits, accumulate);
+  EDRL_LAUNCH_CHECK();
+  return 0;
 }
 
 // The same weight gradient with dy stored as bf16 (dense [N,Ho,Wo,Co]) and x fp32: the stem of the bf16 trunk, whose d_raw comes out

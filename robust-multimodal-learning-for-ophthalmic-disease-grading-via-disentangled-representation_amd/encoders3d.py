@@ -62,30 +62,41 @@ class Conv3dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xu, w = ctx.saved_tensors
+        xs, w = ctx.saved_tensors                          # xs: the volume itself, or its depth-unfolded copy (ctx.unfolded)
         x_shape, KD, sd, s, pd, p = ctx.cfg
-        if not ctx.unfolded:                               # the unfolded operand of the weight gradient is rebuilt here, transiently
-            xu = depth_unfold(xu, KD, sd, pd, w.shape[3])
-        N, Do, H, W, CK = xu.shape
-        dy4 = dy.contiguous().view(N * Do, dy.shape[2], dy.shape[3], dy.shape[4])
-        xu4 = xu.view(N * Do, H, W, CK)
-        dw = ops.conv2d_wgrad(dy4, xu4, tuple(w.shape), s, p) if ctx.needs_input_grad[1] else None
-        dx = None
-        if ctx.needs_input_grad[0]:
-            Nn, D, _, _, C = x_shape
-            Co, KH, KW = w.shape[0], w.shape[1], w.shape[2]
-            Ho, Wo = dy4.shape[1], dy4.shape[2]
-            if CK == KD * C and L.query("edrl_conv3d_dgrad_ok_f32", Nn, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s):
-                # depth taps decoded inside the gather: the k_d x wide unfolded gradient and its fold pass do not exist
-                wt3 = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
-                L.call("edrl_conv3d_dgrad_weight_f32", P(w), P(wt3), Co, KH, KW, KD, C, sd)
-                dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
-                ops._launch_timed("conv_gather", 2.0 * dy4.numel() * KH * KW * KD * C, "edrl_conv3d_ndhwc_dgrad_f32", P(dy4), P(wt3),
-                                  P(dx), Nn, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s, pd, p,
-                                  kernels=sd * s * s, nbytes=4.0 * (dy4.numel() + w.numel() + dx.numel()))
-            else:
-                dxu = ops.conv2d_dgrad(dy4, ops.permute_weight(w), tuple(xu4.shape), s, p)
-                dx = depth_fold(dxu.view(N, Do, H, W, CK), x_shape, KD, sd, pd)
+        N, D, H, W, C = x_shape
+        Co, KH, KW, CK = w.shape
+        Do, Ho, Wo = dy.shape[1], dy.shape[2], dy.shape[3]
+        dy4 = dy.contiguous().view(N * Do, Ho, Wo, Co)
+        need_w, need_x = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
+        # depth taps decoded inside the kernels (no unfolded operand, no k_d x wide unfolded gradient + fold pass) where the geometry
+        # allows; the unfolded form otherwise (the 1-channel stem, odd depths under a depth stride)
+        vol_w = need_w and not ctx.unfolded and bool(L.query("edrl_conv3d_wgrad_ok_f32", N, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW))
+        vol_x = need_x and CK == KD * C and bool(L.query("edrl_conv3d_dgrad_ok_f32", N, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s))
+        xu4 = None
+        if (need_w and not vol_w) or (need_x and not vol_x):
+            xu = xs if ctx.unfolded else depth_unfold(xs, KD, sd, pd, CK)
+            xu4 = xu.view(N * Do, H, W, CK)
+        dw = dx = None
+        if vol_w:
+            dw = torch.empty(tuple(w.shape), device=dy.device, dtype=torch.float32)
+            nb = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N * Do, Ho, Wo, Co, CK, KH, KW)
+            ws = torch.empty(nb // 4, device=dy.device, dtype=torch.float32)
+            ops._launch_timed("conv_wgrad", 2.0 * dy4.numel() * KH * KW * CK, "edrl_conv3d_ndhwc_wgrad_f32", P(dy4), P(xs), P(dw), P(ws),
+                              nb, N, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s, pd, p, 0,
+                              nbytes=4.0 * (dy4.numel() + xs.numel() + dw.numel()))
+        elif need_w:
+            dw = ops.conv2d_wgrad(dy4, xu4, tuple(w.shape), s, p)
+        if vol_x:
+            wt3 = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            L.call("edrl_conv3d_dgrad_weight_f32", P(w), P(wt3), Co, KH, KW, KD, C, sd)
+            dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+            ops._launch_timed("conv_gather", 2.0 * dy4.numel() * KH * KW * KD * C, "edrl_conv3d_ndhwc_dgrad_f32", P(dy4), P(wt3), P(dx),
+                              N, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s, pd, p, kernels=sd * s * s,
+                              nbytes=4.0 * (dy4.numel() + w.numel() + dx.numel()))
+        elif need_x:
+            dxu = ops.conv2d_dgrad(dy4, ops.permute_weight(w), tuple(xu4.shape), s, p)
+            dx = depth_fold(dxu.view(N, Do, H, W, CK), x_shape, KD, sd, pd)
         return dx, dw, None, None, None, None, None
 
 

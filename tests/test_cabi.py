@@ -163,3 +163,13 @@ def test_shipped_library_holds_no_diagnostic_kernels_and_switches_reload(edrl):
     assert fn["edrl_conv3d_fwd_ok_f32"](2, 4, 8, 8, 12, 4, 8, 8, 16, 3, 3, 3) == 0    # Ci % 16 != 0: the unfolded path serves it
     assert fn["edrl_conv3d_fwd_ok_f32"](2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3) == 1
     assert fn["edrl_conv3d_ndhwc_fwd_f32"](None, None, None, 2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3, 1, 1, 1, 1, None) == -22
+    # backward of the same layers: data gradient (Co % 16, Di % dstride, dstride in {1, stride}) and weight gradient (Ci % 4)
+    assert fn["edrl_conv3d_dgrad_ok_f32"](2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3, 1, 1) == 1
+    assert fn["edrl_conv3d_dgrad_ok_f32"](2, 5, 8, 8, 16, 3, 4, 4, 16, 3, 3, 3, 2, 2) == 0    # odd depth under a depth stride
+    assert fn["edrl_conv3d_dgrad_ok_f32"](2, 4, 8, 8, 16, 2, 8, 8, 16, 3, 3, 3, 2, 1) == 0    # depth stride without an in-plane stride
+    assert fn["edrl_conv3d_dgrad_ok_f32"](2, 4, 8, 8, 16, 4, 8, 8, 24, 3, 3, 3, 1, 1) == 0    # Co % 16
+    assert fn["edrl_conv3d_ndhwc_dgrad_f32"](None, None, None, 2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3, 1, 1, 1, 1, None) == -22
+    assert fn["edrl_conv3d_dgrad_weight_f32"](None, None, 16, 3, 3, 3, 16, 1, None) == -22
+    assert fn["edrl_conv3d_wgrad_ok_f32"](2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3) == 1
+    assert fn["edrl_conv3d_wgrad_ok_f32"](2, 4, 8, 8, 6, 4, 8, 8, 16, 3, 3, 3) == 0           # Ci % 4
+    assert fn["edrl_conv3d_ndhwc_wgrad_f32"](None, None, None, None, 0, 2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3, 1, 1, 1, 1, 0, None) == -22
