@@ -456,6 +456,12 @@ int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, floa
                                 int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW, int dstride,
                                 int stride, int dpad, int pad, int accumulate, hipStream_t stream);
 
+/* Kernels of the fp32 implicit-GEMM gather family (conv forward / data gradient / Linear) launched by this process so far.  One
+ * C-ABI call may issue several (one per parity class of a strided data gradient; body + narrow-tile tail when the workgroup count
+ * is just above a multiple of 256, csrc/conv_gemm.hip gather_tail_split); bench.py reads the difference around a call so that its
+ * launch count equals rocprofv3's. */
+long edrl_gather_launch_count(void);
+
 /* Run-time switches (EDRL_* environment variables, csrc/edrl_config.h) are read ONCE at first use; this re-reads them.  For tests
  * and A/B scripts, between launches (not while other threads launch).  Returns 1 if the library was built with -DEDRL_DIAG
  * (diagnostic kernel variants present: libedrl_hip_diag.so), 0 for the shipped library. */

@@ -295,7 +295,7 @@ template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = fa
           bool OUT16 = false, bool VOL = false>
 __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
-    const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherFuse F) {
+    const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherSplit S, GatherFuse F) {
   static_assert(ATR == 0 || BUF, "operand transforms ride on the buffer-descriptor path");
   static_assert(!OUT16 || (EPI == 0 && !DGRAD), "bf16 output: plain forward only");
   static_assert(!VOL || (BUF && FAST && ATR == 0 && EPI == 0 && MASK), "depth taps: plain forward / data gradient on the descriptor path");
@@ -315,7 +315,18 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int lid = edrl_xcd_remap(blockIdx.x, gridDim.x);
+  // K-split tail (GatherSplit, gather_ksplit_plan): workgroups past S.n_body each run 1/ksplit of the K loop of a tail tile and
+  // leave their accumulators in S.slab (part >= 0); the fix-up launch (mode 2) sums the slabs in part order and runs the epilogue.
+  int lid, part = -1;
+  if (S.mode == 1 && (int)blockIdx.x >= S.n_body) {
+    const int sub = (int)blockIdx.x - S.n_body;
+    lid = S.n_body + sub / S.ksplit;
+    part = sub - (sub / S.ksplit) * S.ksplit;
+  } else if (S.mode == 2) {
+    lid = S.n_body + (int)blockIdx.x;
+  } else {
+    lid = edrl_xcd_remap(blockIdx.x, S.mode == 1 ? (unsigned)S.n_body : gridDim.x);
+  }
   const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
@@ -425,6 +436,20 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
       rowoff[i] = ok ? (((long)rn[i] * g.SH + sh) * g.SW + sw) * g.ld_src : -1;
     }
   };
+  const int KT = (g.Ktot + BKT - 1) / BKT;
+  int kt0 = 0, kt1 = KT;
+  if (S.mode == 2) kt1 = 0;                 // fix-up: no K loop, the accumulators come from the slabs
+  if constexpr (BUF && FAST) {
+    if (part >= 0) {                        // this workgroup's share of the K tiles; decode state of its first tile
+      kt0 = part * S.kt_per;
+      kt1 = kt0 + S.kt_per < KT ? kt0 + S.kt_per : KT;
+      const int k0 = kt0 * BKT;
+      int tq = k0 / g.SC;
+      cb = k0 - tq * g.SC;
+      if constexpr (VOL) { td = tq % g.KD; tq /= g.KD; }
+      ta = tq / g.KWs; tb = tq - ta * g.KWs;
+    }
+  }
   if (FAST) retap();
   auto advance = [&]() {
     if constexpr (BUF) {   // the tap change is decided on the uniform part of the channel offset: a scalar branch
@@ -550,7 +575,6 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = (g.Ktot + BKT - 1) / BKT;
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) load_piece(i);
   load_params();
@@ -559,8 +583,8 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   __syncthreads();
 
   const int li = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
     advance();   // decode state of tile kt+1 (past the end: kvalid is false and the pieces load zeros)
     const float* a = As + buf * BM * LDKT + (wm0 + li) * LDKT + 4 * lh;
     const float* b = Bs + buf * BN * LDKT + (wn0 + li) * LDKT + 4 * lh;
@@ -624,6 +648,30 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
     __syncthreads();
   }
 
+  if (S.mode != 0) {
+    constexpr int NE = TM * TN * 16;         // accumulator floats per lane
+    if (part >= 0) {                         // partial K range: accumulators -> slab [(tail tile, part)][element][thread]
+      float* sl = S.slab + ((long)((int)blockIdx.x - S.n_body) * NE) * 256 + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sl[((i * TN + j) * 16 + r) * 256] = acc[i][j][r];
+      return;
+    }
+    if (S.mode == 2) {                       // fix-up: parts summed in part order (fixed order: deterministic)
+      for (int p = 0; p < S.ksplit; ++p) {
+        const float* sl = S.slab + ((long)((int)blockIdx.x * S.ksplit + p) * NE) * 256 + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += sl[((i * TN + j) * 16 + r) * 256];
+      }
+    }
+  }
   const bool relu = g.flags & GF_RELU, accum = g.flags & GF_ACCUM;
   if (g.flags & GF_VEC_EPI) {
     // Vector epilogue: each wave transposes its accumulators through LDS (the K-loop buffers are free now) so that a
@@ -935,12 +983,25 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   }
 }
 
+// kernels of the gather family issued by this process (edrl_gather_launch_count): a call may issue several (parity classes of a
+// strided data gradient, body + tail of a split call); the bench's timer reads the difference around a call so that its launch
+// count is the one rocprofv3 sees
+static long g_gather_launches = 0;
+
 template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
           bool OUT16 = false, bool VOL = false>
 static int launch_gather_v2(const float* src, const float* wm, float* dst, const float* bias,
-                            const float* mul, const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr) {
+                            const float* mul, const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr,
+                            const GatherSplit* split = nullptr) {
   const int tiles_m = edrl_cdiv(g.M, BM), tiles_n = edrl_cdiv(g.NC, BN);
-  const long nblk = (long)tiles_m * tiles_n;
+  GatherSplit S;
+  memset(&S, 0, sizeof(S));
+  long nblk = (long)tiles_m * tiles_n;
+  if (split) {
+    S = *split;
+    const long tail = nblk - S.n_body;      // tail tiles: K-split in the main launch (mode 1), finished by the fix-up launch (mode 2)
+    nblk = S.mode == 1 ? S.n_body + tail * S.ksplit : tail;
+  }
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
   const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
@@ -961,9 +1022,53 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
     const long ldmax = (fuse && fuse->ld_ep > g.ld_dst) ? fuse->ld_ep : g.ld_dst;
     if (DGRAD && g.step > 1 && ohw > 0 && (BM / ohw + 2) * g.OH * g.OW * ldmax * 4 < (1L << 31)) gm.flags |= GF_LEAN_STRIDED;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, gm, tiles_n, F);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, gm, tiles_n, S, F);
+  ++g_gather_launches;
   EDRL_LAUNCH_CHECK();
   return 0;
+}
+
+// Partial last quantum.  With 4 (3) workgroups resident per CU a launch takes ceil(workgroups / 256) workgroup times on the busiest
+// CU: 1568 tiles of 128 x 128 (l4 at 1024 images) cost as much as 1792 (scripts/tail_sweep.py: the time steps every 256
+// workgroups, 137 TFLOP/s at exact multiples, 121 at 6.12 x 256).  When the tail beyond the last multiple of 256 is at most 128
+// tiles, each tail tile's K loop is split over floor(256 / tail) workgroups appended to the SAME launch (they fill the last
+// quantum with 1/ksplit of a tile's work each and leave their accumulators in a slab), and a second, short launch of the same
+// kernel sums the slabs in a fixed order and runs the tile's ordinary epilogue (statistics, masks, accumulate: every variant).
+// Deterministic; not bit-identical to the unsplit kernel on the tail tiles (the K sum is associated differently).
+// Measured and dropped on the way: the tail as 128 x 64 tiles in a second launch (+1..2 % only: the body's ragged end and the
+// launch boundary eat the gain; the narrow tile itself is 8-10 % slower).
+static hipStream_t g_slab_stream[8];
+static float* g_slab_ptr[8];
+static int g_slab_n = 0;
+static const size_t GATHER_SLAB_BYTES = (size_t)256 * 128 * 128 * sizeof(float);     // 256 split workgroups x one 128 x 128 tile
+static float* gather_slab(hipStream_t st) {      // one slab per stream the family is launched on (launches of a stream are ordered)
+  for (int i = 0; i < g_slab_n; ++i)
+    if (g_slab_stream[i] == st) return g_slab_ptr[i];
+  if (g_slab_n >= 8) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, GATHER_SLAB_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  g_slab_stream[g_slab_n] = st; g_slab_ptr[g_slab_n] = (float*)p;
+  return g_slab_ptr[g_slab_n++];
+}
+static bool gather_ksplit_plan(const GatherGeom& g, hipStream_t st, GatherSplit* S) {
+  if (!edrl_cfg().gather_tail_split) return false;
+  const int tiles_m = edrl_cdiv(g.M, 128), tiles_n = edrl_cdiv(g.NC, 128);
+  if (tiles_n <= 0 || tiles_n > 256 || (256 % tiles_n)) return false;
+  const int per = 256 / tiles_n;                         // row tiles per 256 workgroups
+  const int body = tiles_m / per * per;
+  const long tail = (long)(tiles_m - body) * tiles_n;    // tail workgroups
+  if (body == 0 || tail == 0 || tail > 128) return false;
+  const int KT = edrl_cdiv(g.Ktot, 16);
+  int ks = (int)(256 / tail);
+  if (ks > 8) ks = 8;
+  while (ks > 1 && edrl_cdiv(KT, ks) < 8) --ks;          // >= 8 K tiles per part
+  if (ks < 2) return false;
+  // worth it only when the saved part of a tile time ((1 - 1/ks) x ~61 ns per K element, measured) exceeds the fix-up launch (~30 us)
+  if ((long)g.Ktot * (ks - 1) / ks < 640) return false;
+  float* slab = gather_slab(st);
+  if (!slab) return false;
+  S->mode = 1; S->n_body = body * tiles_n; S->ksplit = ks; S->kt_per = edrl_cdiv(KT, ks); S->slab = slab;
+  return true;
 }
 
 // The fused-BatchNorm variants exist on the buffer-descriptor fast path only: report whether a geometry qualifies.
@@ -989,6 +1094,16 @@ static int dispatch_gather_fused(const float* src, const float* wm, float* dst, 
     if (mask) return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
     return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
   }
+  GatherSplit S;
+  if (gather_ksplit_plan(g, st, &S)) {
+    for (int mode = 1; mode <= 2; ++mode) {
+      S.mode = mode;
+      const int rc = mask ? launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F, &S)
+                          : launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F, &S);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (mask) return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
   return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
 }
@@ -1008,6 +1123,7 @@ static int launch_gather(const float* src, const float* wm, float* dst, const fl
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, src, wm, dst, bias, mul, g, tiles_n);
+  ++g_gather_launches;
   EDRL_LAUNCH_CHECK();
   return 0;
 }
@@ -1134,6 +1250,15 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
                        (long)g.NC * g.Kfull * 4 < (1L << 31);   // (rows < 2^31: checked by the extern "C" launchers)
       if (buf && variant != 5) {   // 4 workgroups per CU (123 VGPRs, 4 x 40 KiB = all of the LDS): +2-3 % over 3 per CU (variant 5)
         if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st);
+        GatherSplit S;
+        if (gather_ksplit_plan(g, st, &S)) {
+          for (int mode = 1; mode <= 2; ++mode) {
+            S.mode = mode;
+            const int rc = launch_gather_v2<128, 128, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st, nullptr, &S);
+            if (rc) return rc;
+          }
+          return 0;
+        }
         return launch_gather_v2<128, 128, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st);
       }
       if (buf) {
@@ -1649,6 +1774,9 @@ __global__ void permute_021_kernel(const float* __restrict__ in, float* __restri
 }
 
 extern "C" {
+
+// Kernels of the fp32 implicit-GEMM gather family launched by this process so far (diagnostic: bench.py's per-launch averages).
+long edrl_gather_launch_count(void) { return g_gather_launches; }
 
 // Convolution forward on NHWC fp32 (also any Linear: KH=KW=1, H=W=1, N=rows).
 // y[n,ho,wo,co] = act( sum x[n,ho*s-p+kh,wo*s-p+kw,ci] * w[co,kh,kw,ci] + bias[co] ) * mul + (accum ? y : 0)

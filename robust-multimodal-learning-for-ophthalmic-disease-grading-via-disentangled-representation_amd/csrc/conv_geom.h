@@ -63,6 +63,14 @@ struct GatherFuse {
   int ep_chunk0;               //        first chunk of this launch (parity classes of a strided data gradient)
 };
 
+// K-split of the tail tiles of a launch (conv_gemm.hip gather_ksplit_plan; fp32 gather kernel only)
+struct GatherSplit {
+  int mode;                    // 0: off; 1: main launch (body tiles + the split workgroups); 2: fix-up launch over the tail tiles
+  int n_body;                  // workgroups (= tiles) of the body, a multiple of 256
+  int ksplit, kt_per;          // parts per tail tile, K tiles per part
+  float* slab;                 // [tail tile][part][accumulator element][thread] fp32
+};
+
 #define GF_RELU 1
 #define GF_ACCUM 2
 #define GF_VEC_EPI 4   // set by the host when the float4 epilogue is legal (alignment, NC % 4 == 0)

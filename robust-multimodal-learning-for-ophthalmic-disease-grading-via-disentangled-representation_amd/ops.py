@@ -103,10 +103,12 @@ def _launch_timed(kind, flops, name, *args, kernels=1, nbytes=0.0):
         L.call(name, *args)
         return
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    k0 = L.query("edrl_gather_launch_count")
     e0.record()
     L.call(name, *args)
     e1.record()
-    _timer.add(kind, flops, e0, e1, kernels, nbytes)
+    k1 = L.query("edrl_gather_launch_count")
+    _timer.add(kind, flops, e0, e1, (k1 - k0) if k1 > k0 else kernels, nbytes)     # fp32 gather family: the launches actually issued
 
 
 def call_timed_bytes(kind, nbytes, name, *args, kernels=1):
