@@ -20,6 +20,7 @@
 // Global->LDS is register staged and double buffered (one barrier per K tile):
 // tile t+1's loads are issued before tile t's MFMAs and written after them.
 #include "edrl_common.h"
+#include <mutex>
 #include "edrl_config.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -1041,7 +1042,9 @@ static hipStream_t g_slab_stream[8];
 static float* g_slab_ptr[8];
 static int g_slab_n = 0;
 static const size_t GATHER_SLAB_BYTES = (size_t)256 * 128 * 128 * sizeof(float);     // 256 split workgroups x one 128 x 128 tile
+static std::mutex g_slab_mutex;
 static float* gather_slab(hipStream_t st) {      // one slab per stream the family is launched on (launches of a stream are ordered)
+  std::lock_guard<std::mutex> lock(g_slab_mutex);
   for (int i = 0; i < g_slab_n; ++i)
     if (g_slab_stream[i] == st) return g_slab_ptr[i];
   if (g_slab_n >= 8) return nullptr;

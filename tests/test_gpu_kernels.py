@@ -460,6 +460,74 @@ def test_conv_fused_bn_statistics(edrl, dev, case):
     check("fused_running_var", rv.cpu(), 0.9 + 0.1 * yd.var(0, unbiased=True), 1e-5)
 
 
+def test_gather_ksplit_tail(edrl, dev, switches):
+    """Workgroup counts just above a multiple of 256 (csrc/conv_gemm.hip gather_ksplit_plan): the tail tiles' K loops are split over
+    the workgroups of the last quantum and a fix-up launch sums the slabs and runs the ordinary epilogue.  272 row tiles x 2 column
+    tiles here = 512 body workgroups + 32 tail tiles x 8 parts.  The body rows must be bit-identical to the unsplit kernel, the tail rows equal up to the
+    association of the K sum, everything within 2e-5 of fp64; statistics, masks, accumulation and chunk partials of the fused
+    epilogues come out of the fix-up launch."""
+    import torch.nn.functional as F
+    ops, L = edrl.ops, edrl._lib
+    N, H, C, Co = 34, 32, 256, 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, H, C, generator=g).to(dev)
+    w = (torch.randn(Co, 3, 3, C, generator=g) * 0.05).to(dev)
+    dy = torch.randn(N, H, H, Co, generator=g).to(dev)
+    wt = ops.permute_weight(w)
+    shift = torch.zeros(Co, device=dev)
+    # operands of the fused data gradient: d_raw = A*g + nK2*yraw + C2 on the way in; mask by relu(bn(raw_lo)) + accumulate + sums on the way out
+    yraw = torch.randn(N, H, H, Co, generator=g).to(dev)
+    bcoef = torch.stack([torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1, torch.randn(Co, generator=g) * 0.1,
+                         torch.randn(Co, generator=g) * 0.1]).to(dev)
+    raw_lo = torch.randn(N, H, H, C, generator=g).to(dev)
+    sc, sh, mu = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.2
+    fcoef = torch.stack([mu, torch.ones(C), sc, sh, sh - mu * sc]).to(dev)
+    base = torch.randn(N, H, H, C, generator=g).to(dev)
+    res = {}
+    for sp in ("0", "1"):
+        switches(EDRL_GATHER_TAIL_SPLIT=sp)
+        k0 = L.query("edrl_gather_launch_count")
+        y = ops.conv2d_fwd(x, w, stride=1, pad=1)
+        launches = L.query("edrl_gather_launch_count") - k0
+        assert launches == (2 if sp == "1" else 1), launches
+        ys, part, chunks = ops.conv2d_fwd_stats(x, w, shift, 1, 1)
+        assert torch.equal(ys, y)
+        dx = ops.conv2d_dgrad(dy, wt, tuple(x.shape), 1, 1)
+        out = base.clone()
+        dxe, epart, echunks = ops.conv2d_dgrad_bn(dy, yraw, bcoef, wt, tuple(x.shape), 1, 1, out=out, accumulate=True,
+                                                  ep=(raw_lo, None, fcoef, True))
+        res[sp] = (y, part.clone(), dx, dxe.clone(), epart.clone())
+    body = 256 * 128                                    # rows of the body tiles
+    for i, name in ((0, "fwd"), (2, "dgrad"), (3, "dgrad_bn")):
+        a, b = res["1"][i].view(-1, res["1"][i].shape[-1]), res["0"][i].view(-1, res["0"][i].shape[-1])
+        assert torch.equal(a[:body], b[:body]), name
+        assert not torch.equal(a[body:], b[body:]), name + ": the tail was not split"
+        check("ksplit_" + name, a.cpu(), b.cpu(), 5e-6)
+    M = N * H * H
+    yd = F.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.cpu().double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    check("ksplit_fwd_fp64", res["1"][0].cpu(), yd, 2e-5)
+    part = res["1"][1].double().cpu()                   # [chunks][3][Co]: sum (y - K), sum (y - K)^2, K per 128-row chunk
+    mean = (part[:, 0] + 128.0 * part[:, 2]).sum(0) / M
+    check("ksplit_stats_mean", mean, yd.reshape(M, Co).mean(0), 1e-5)
+    dxd = F.conv_transpose2d(dy.cpu().double().permute(0, 3, 1, 2), w.cpu().double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    check("ksplit_dgrad_fp64", res["1"][2].cpu(), dxd, 2e-5)
+    # fused variant against fp64: d_raw -> transpose conv -> + base -> mask -> chunk sums
+    bc = bcoef.cpu().double()
+    draw = bc[0] * dy.cpu().double() + bc[1] * yraw.cpu().double() + bc[2]
+    ge = F.conv_transpose2d(draw.permute(0, 3, 1, 2), w.cpu().double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1) + base.cpu().double()
+    keep = torch.addcmul(fcoef[4].cpu().double(), raw_lo.cpu().double(), fcoef[2].cpu().double()) > 0
+    # decisions within rounding of zero may flip in fp32: compare where the pre-activation is not tiny
+    pre = torch.addcmul(fcoef[4].cpu().double(), raw_lo.cpu().double(), fcoef[2].cpu().double()).abs()
+    sure = pre > 1e-5
+    got = res["1"][3].cpu().double()
+    ref = torch.where(keep, ge, torch.zeros_like(ge))
+    err = ((got - ref).abs() * sure).max() / ref.abs().max()
+    assert float(err) < 2e-5, float(err)
+    ep = res["1"][4].double().cpu()                     # [chunks][2][C]: sum g, sum g*(x - mean)
+    check("ksplit_epart_sum_g", ep[:, 0].sum(0), got.reshape(M, C).sum(0), 2e-5)
+    check("ksplit_epart_sum_gx", ep[:, 1].sum(0), (got * (raw_lo.cpu().double() - fcoef[0].cpu().double())).reshape(M, C).sum(0), 2e-5)
+
+
 def test_fused_adam_vs_torch_adam(edrl, dev):
     """edrl_adam_multi_f32 (one launch for all tensors) against torch.optim.Adam(lr, weight_decay=1e-6) of
     fusion_train.py:747 over 5 steps: odd sizes, a tensor larger than one chunk, one parameter that never gets a
