@@ -30,7 +30,7 @@ static void load(EdrlConfig& c) {
   c.wgrad_fast = env_int("EDRL_WGRAD_FAST", 1);
   c.wgrad_target = env_long("EDRL_WGRAD_TARGET", 0L);
   c.narrow_below = env_int("EDRL_NARROW_BELOW", 512);
-  c.gather_tail_split = env_int("EDRL_GATHER_TAIL_SPLIT", 1);
+  c.gather_tail_split = env_int("EDRL_GATHER_TAIL_SPLIT", 2);
   c.linear_smallm = env_int("EDRL_LINEAR_SMALLM", 1);
   c.gather_variant = env_int("EDRL_GATHER_VARIANT", 1);
   c.diag_v3 = env_int("EDRL_V3_DBG", 0);

@@ -1053,14 +1053,14 @@ static float* gather_slab(hipStream_t st) {      // one slab per stream the fami
   g_slab_stream[g_slab_n] = st; g_slab_ptr[g_slab_n] = (float*)p;
   return g_slab_ptr[g_slab_n++];
 }
-static bool gather_ksplit_plan(const GatherGeom& g, hipStream_t st, GatherSplit* S) {
+static bool gather_ksplit_plan(const GatherGeom& g, hipStream_t st, GatherSplit* S, int bn) {
   if (!edrl_cfg().gather_tail_split) return false;
-  const int tiles_m = edrl_cdiv(g.M, 128), tiles_n = edrl_cdiv(g.NC, 128);
+  const int tiles_m = edrl_cdiv(g.M, 128), tiles_n = edrl_cdiv(g.NC, bn);
   if (tiles_n <= 0 || tiles_n > 256 || (256 % tiles_n)) return false;
   const int per = 256 / tiles_n;                         // row tiles per 256 workgroups
   const int body = tiles_m / per * per;
-  const long tail = (long)(tiles_m - body) * tiles_n;    // tail workgroups
-  if (body == 0 || tail == 0 || tail > 128) return false;
+  const long tail = (long)(tiles_m - body) * tiles_n;    // tail workgroups (body == 0: a grid that leaves half of the CUs idle)
+  if (tail == 0 || tail > 128 || (body == 0 && edrl_cfg().gather_tail_split < 2)) return false;
   const int KT = edrl_cdiv(g.Ktot, 16);
   int ks = (int)(256 / tail);
   if (ks > 8) ks = 8;
@@ -1072,6 +1072,21 @@ static bool gather_ksplit_plan(const GatherGeom& g, hipStream_t st, GatherSplit*
   if (!slab) return false;
   S->mode = 1; S->n_body = body * tiles_n; S->ksplit = ks; S->kt_per = edrl_cdiv(KT, ks); S->slab = slab;
   return true;
+}
+
+// One call = one launch, or (K-split tail) the main launch + its fix-up launch
+template <int BN, bool DGRAD, int OCC, int ATR = 0, int EPI = 0, bool MASK = true>
+static int launch_gather_split(const float* src, const float* wm, float* dst, const float* bias, const float* mul,
+                               const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr) {
+  GatherSplit S;
+  if (!gather_ksplit_plan(g, st, &S, BN))
+    return launch_gather_v2<128, BN, DGRAD, 16, OCC, true, true, ATR, EPI, MASK>(src, wm, dst, bias, mul, g, st, fuse);
+  for (int mode = 1; mode <= 2; ++mode) {
+    S.mode = mode;
+    const int rc = launch_gather_v2<128, BN, DGRAD, 16, OCC, true, true, ATR, EPI, MASK>(src, wm, dst, bias, mul, g, st, fuse, &S);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 // The fused-BatchNorm variants exist on the buffer-descriptor fast path only: report whether a geometry qualifies.
@@ -1094,21 +1109,11 @@ static int dispatch_gather_fused(const float* src, const float* wm, float* dst, 
   const bool narrow = g.NC <= 64 || ((long)edrl_cdiv(g.M, 128) * edrl_cdiv(g.NC, 128) < small_grid);
   const bool mask = !(g.KH == 1 && g.KW == 1 && g.pad == 0);   // 1x1 / pad 0: no padding taps, no masked rows below M
   if (narrow) {
-    if (mask) return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
-    return launch_gather_v2<128, 64, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
+    if (mask) return launch_gather_split<64, DGRAD, FUSED_OCC, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
+    return launch_gather_split<64, DGRAD, FUSED_OCC, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
   }
-  GatherSplit S;
-  if (gather_ksplit_plan(g, st, &S)) {
-    for (int mode = 1; mode <= 2; ++mode) {
-      S.mode = mode;
-      const int rc = mask ? launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F, &S)
-                          : launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F, &S);
-      if (rc) return rc;
-    }
-    return 0;
-  }
-  if (mask) return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
-  return launch_gather_v2<128, 128, DGRAD, 16, FUSED_OCC, true, true, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
+  if (mask) return launch_gather_split<128, DGRAD, FUSED_OCC, ATR, EPI, true>(src, wm, dst, nullptr, nullptr, g, st, &F);
+  return launch_gather_split<128, DGRAD, FUSED_OCC, ATR, EPI, false>(src, wm, dst, nullptr, nullptr, g, st, &F);
 }
 
 template <int BM, int BN, bool DGRAD, bool VEC>
@@ -1252,17 +1257,8 @@ static int dispatch_gather(const float* src, const float* wm, float* dst, const 
       const bool buf = buf_env && ohw > 0 && (128 / ohw + 2) * g.SH * g.SW * g.ld_src * 4 < (1L << 31) &&
                        (long)g.NC * g.Kfull * 4 < (1L << 31);   // (rows < 2^31: checked by the extern "C" launchers)
       if (buf && variant != 5) {   // 4 workgroups per CU (123 VGPRs, 4 x 40 KiB = all of the LDS): +2-3 % over 3 per CU (variant 5)
-        if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st);
-        GatherSplit S;
-        if (gather_ksplit_plan(g, st, &S)) {
-          for (int mode = 1; mode <= 2; ++mode) {
-            S.mode = mode;
-            const int rc = launch_gather_v2<128, 128, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st, nullptr, &S);
-            if (rc) return rc;
-          }
-          return 0;
-        }
-        return launch_gather_v2<128, 128, DGRAD, 16, 4, true, true>(src, wm, dst, bias, mul, g, st);
+        if (narrow) return launch_gather_split<64, DGRAD, 4>(src, wm, dst, bias, mul, g, st);
+        return launch_gather_split<128, DGRAD, 4>(src, wm, dst, bias, mul, g, st);
       }
       if (buf) {
         if (narrow) return launch_gather_v2<128, 64, DGRAD, 16, 3, true, true>(src, wm, dst, bias, mul, g, st);

@@ -27,7 +27,7 @@ struct EdrlConfig {
   int wgrad_fast;        // EDRL_WGRAD_FAST       0: generic row decode in the weight gradient
   long wgrad_target;     // EDRL_WGRAD_TARGET     split-K workgroup target override (0 = automatic)
   int narrow_below;      // EDRL_NARROW_BELOW     grids below this many workgroups use 64-wide N tiles (512)
-  int gather_tail_split; // EDRL_GATHER_TAIL_SPLIT  fp32 gather: K-split of the tiles of a last partial quantum (<= 128 of 256 workgroups) + fix-up launch (1)
+  int gather_tail_split; // EDRL_GATHER_TAIL_SPLIT  fp32 gather: K-split of the tiles of a last partial quantum (<= 128 of 256 workgroups) + fix-up launch; 2: also of grids of <= 128 workgroups (2)
   int linear_smallm;     // EDRL_LINEAR_SMALLM    0: rows <= 64 Linear layers on the 128-row tiles
   int gather_variant;    // EDRL_GATHER_VARIANT   0 | 1 | 3 | 5: workgroups per CU of the gather kernel (1 = automatic)
   // diagnostic kernels: compiled only with -DEDRL_DIAG (make diag -> libedrl_hip_diag.so, never the shipped library)
