@@ -528,6 +528,47 @@ def test_gather_ksplit_tail(edrl, dev, switches):
     check("ksplit_epart_sum_gx", ep[:, 1].sum(0), (got * (raw_lo.cpu().double() - fcoef[0].cpu().double())).reshape(M, C).sum(0), 2e-5)
 
 
+def test_gather_ksplit_small_grids(edrl, dev, switches):
+    """Grids of <= 128 workgroups are K-split as a whole (EDRL_GATHER_TAIL_SPLIT=2): a Linear layer with the bias + ReLU + mask
+    epilogue and its accumulate form, and the parity classes of a strided 3x3 data gradient (4-tap class split, 2-/1-tap classes
+    below the K rule: a mix in one call), against fp64 and against the unsplit kernel."""
+    ops, L = edrl.ops, edrl._lib
+    g = torch.Generator().manual_seed(9)
+    rows, cin, cout = 1000, 2048, 1024                 # 8 row tiles x 16 narrow column tiles = 128 workgroups -> 2 parts of K = 2048
+    x = torch.randn(rows, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) * 0.03
+    b = torch.randn(cout, generator=g)
+    mask = (torch.rand(rows, cout, generator=g) > 0.2).float() / 0.8
+    ref = F.relu(x.double() @ w.double().t() + b.double()) * mask.double()
+    res = {}
+    for sp in ("0", "2"):
+        switches(EDRL_GATHER_TAIL_SPLIT=sp)
+        k0 = L.query("edrl_gather_launch_count")
+        res[sp] = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), mask.to(dev), relu=True)
+        assert L.query("edrl_gather_launch_count") - k0 == (2 if sp == "2" else 1)
+    check("ksplit_linear_fp64", res["2"].cpu(), ref, 2e-5)
+    check("ksplit_linear_vs_unsplit", res["2"].cpu(), res["0"].cpu(), 5e-6)
+    assert not torch.equal(res["2"], res["0"])
+    # strided data gradient: x [8,28,28,256], 3x3 / stride 2 / pad 1 -> dy [8,14,14,256]
+    N, H, C, Co = 8, 28, 256, 256
+    wc = (torch.randn(Co, 3, 3, C, generator=g) * 0.05)
+    dy = torch.randn(N, 14, 14, Co, generator=g)
+    base = torch.randn(N, H, H, C, generator=g)
+    dxd = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), wc.double().permute(0, 3, 1, 2), stride=2, padding=1,
+                             output_padding=1).permute(0, 2, 3, 1) + base.double()
+    wt = ops.permute_weight(wc.to(dev))
+    out = {}
+    for sp in ("0", "2"):
+        switches(EDRL_GATHER_TAIL_SPLIT=sp)
+        o = base.to(dev).clone()
+        k0 = L.query("edrl_gather_launch_count")
+        ops.conv2d_dgrad(dy.to(dev), wt, (N, H, H, C), 2, 1, out=o, accumulate=True)
+        out[sp] = (o, L.query("edrl_gather_launch_count") - k0)
+    assert out["0"][1] == 4 and out["2"][1] == 5, (out["0"][1], out["2"][1])     # four parity classes; the 4-tap class is split
+    check("ksplit_strided_dgrad_fp64", out["2"][0].cpu(), dxd, 2e-5)
+    check("ksplit_strided_dgrad_vs_unsplit", out["2"][0].cpu(), out["0"][0].cpu(), 5e-6)
+
+
 def test_fused_adam_vs_torch_adam(edrl, dev):
     """edrl_adam_multi_f32 (one launch for all tensors) against torch.optim.Adam(lr, weight_decay=1e-6) of
     fusion_train.py:747 over 5 steps: odd sizes, a tensor larger than one chunk, one parameter that never gets a
