@@ -457,9 +457,13 @@ int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, floa
                                 int stride, int dpad, int pad, int accumulate, hipStream_t stream);
 
 /* Kernels of the fp32 implicit-GEMM gather family (conv forward / data gradient / Linear) launched by this process so far.  One
- * C-ABI call may issue several (one per parity class of a strided data gradient; body + narrow-tile tail when the workgroup count
- * is just above a multiple of 256, csrc/conv_gemm.hip gather_tail_split); bench.py reads the difference around a call so that its
- * launch count equals rocprofv3's. */
+ * C-ABI call may issue several: one per parity class of a strided data gradient, and main + fix-up launch when the tiles of a last
+ * partial quantum (workgroup count just above a multiple of 256, or at most 128 in all) are K-split (csrc/conv_gemm.hip
+ * gather_ksplit_plan, switch EDRL_GATHER_TAIL_SPLIT); bench.py reads the difference around a call so that its launch count equals
+ * rocprofv3's.
+ * Library-owned device memory: the K-split keeps one 16 MiB slab per stream the family is launched on (hipMalloc at the first
+ * split call on that stream, at most 8 streams, never freed; a failed allocation just disables the split).  Every other
+ * workspace of this ABI is the caller's. */
 long edrl_gather_launch_count(void);
 
 /* Run-time switches (EDRL_* environment variables, csrc/edrl_config.h) are read ONCE at first use; this re-reads them.  For tests
