@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — EDRL training-step throughput on MI355X (contract: see the task's bench.py section).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C0|C1|C2|C3|C4|C1-3D] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C0|C1|C2|C3|C4|C1-3D|C2-3D] [--batch B]
   N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one synthetic batch: zero_grad -> forward(low view) ->
@@ -45,6 +45,8 @@ CONFIGS = {
     # volume dropped (zeros), bf16 encoders.
     # C1 shapes with the true 3-D-conv OCT encoder (ResNet3D-18 over the 32x224x224 volume)
     "C1-3D": (32, 50, 224, 32, "fp32", "C1-3D: B=32/GPU, ResNet-50 fundus encoder + ResNet3D-18 OCT volume encoder, 224x224 fundus + 32-slice OCT, fp32"),
+    "C2-3D": (64, 50, 224, 32, "bf16", "C2-3D: B=64/GPU, bf16 ResNet-50 fundus encoder + ResNet3D-18 OCT volume encoder with bf16 residual stages, "
+                                       "224x224 fundus + 32-slice OCT"),
     "C4": (4, 50, 512, 128, "bf16", "C4: B=4/GPU, ResNet-50 bf16 encoders, 512x512 fundus + 128-slice OCT, OCT-dropped second view"),
 }
 RECOMPUTE = {"C3"}     # configs that run with args.activation_recompute (encoders.ResNetTrunk.recompute_out)
@@ -208,7 +210,7 @@ def main():
             B = batch
         # strict_labels keeps its default ("deferred": violation flag on the device, raised by raise_on_bad_labels() below)
         args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=depth, activation_recompute=rec,
-                                     encoder_dtype=enc_dtype, oct_encoder="3d" if cfg == "C1-3D" else "slices", oct3d_depth=18)
+                                     encoder_dtype=enc_dtype, oct_encoder="3d" if cfg.endswith("-3D") else "slices", oct3d_depth=18)
         torch.manual_seed(0)
         model = edrl_amd.MedFusion(2, 2, None, args).to(dev).train()
         edrl_amd.broadcast_parameters(model)

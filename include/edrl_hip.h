@@ -412,6 +412,10 @@ int edrl_depth_unfold_f32(const float* x, float* y, int N, int D, long P, int C,
                           hipStream_t stream);
 int edrl_depth_fold_f32(const float* dy, float* dx, int N, int D, long P, int C, int KD, int sd, int pd, int Do, int CK,
                         hipStream_t stream);
+/* The same pair on bf16 tensors (the bf16 3-D trunk, encoders3d.py: its convolutions run on the bf16 MFMA kernels over the
+ * depth-unfolded operand): C % 8 == 0, unfolded width exactly KD*C, 16-byte aligned; the fold sums its taps in fp32 and rounds once. */
+int edrl_depth_unfold_bf16(const void* x_bf16, void* y_bf16, int N, int D, long P, int C, int KD, int sd, int pd, int Do, hipStream_t stream);
+int edrl_depth_fold_bf16(const void* dy_bf16, void* dx_bf16, int N, int D, long P, int C, int KD, int sd, int pd, int Do, hipStream_t stream);
 /* Depth half of MaxPool3d(3, stride 2, pad 1) on [N,D,PC] (PC = H*W*C); idx = winning tap 0..2. */
 int edrl_maxpool_depth3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int D, long PC, hipStream_t stream);
 int edrl_maxpool_depth3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int N, int D, long PC,

@@ -76,6 +76,58 @@ __global__ __launch_bounds__(256) void depth_fold_kernel(const float* __restrict
   }
 }
 
+// bf16 storage (the bf16 3-D trunk): 8 channels (16 bytes) per lane; the fold sums its <= KD taps in fp32 and rounds once
+typedef unsigned short vol_u16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void depth_unfold_h8_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                              int N, int D, int Do, long P, int C, int KD, int sd, int pd) {
+  const int C8 = C >> 3, CK8 = KD * C8;
+  const long total = (long)N * Do * P * CK8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % CK8);
+    long t = i / CK8;
+    const long p = t % P;
+    t /= P;
+    const int dout = (int)(t % Do);
+    const int n = (int)(t / Do);
+    const int kd = j / C8, c8 = j - kd * C8;
+    const int di = dout * sd - pd + kd;
+    vol_u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (di >= 0 && di < D) v = *reinterpret_cast<const vol_u16x8*>(x + (((long)n * D + di) * P + p) * C + c8 * 8);
+    *reinterpret_cast<vol_u16x8*>(y + i * 8) = v;
+  }
+}
+__global__ __launch_bounds__(256) void depth_fold_h8_kernel(const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx,
+                                                            int N, int D, int Do, long P, int C, int KD, int sd, int pd) {
+  const int C8 = C >> 3;
+  const long CK = (long)KD * C;
+  const long total = (long)N * D * P * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long t = i / C8;
+    const long p = t % P;
+    t /= P;
+    const int di = (int)(t % D);
+    const int n = (int)(t / D);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int kd = 0; kd < KD; ++kd) {
+      const int num = di + pd - kd;
+      if (num < 0 || num % sd) continue;
+      const int dout = num / sd;
+      if (dout >= Do) continue;
+      const vol_u16x8 v = *reinterpret_cast<const vol_u16x8*>(dy + (((long)n * Do + dout) * P + p) * CK + (long)kd * C + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += __uint_as_float((unsigned)v[e] << 16);
+    }
+    vol_u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                    // round to nearest even (finite values; NaN stays NaN)
+      const unsigned u = __float_as_uint(s[e]);
+      o[e] = (s[e] != s[e]) ? (unsigned short)0x7fc0 : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    *reinterpret_cast<vol_u16x8*>(dx + i * 8) = o;
+  }
+}
+
 // max over depth, kernel 3 / stride 2 / pad 1 (the depth half of MaxPool3d(3, 2, 1); the spatial half is the 2-D max-pool of
 // bn_pool.hip applied per slice -- max is separable).  idx: which of the 3 taps won (first maximum, like torch).
 __global__ __launch_bounds__(256) void maxpool_depth_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -138,6 +190,23 @@ int edrl_depth_fold_f32(const float* dy, float* dx, int N, int D, long P, int C,
   if (N <= 0 || D <= 0 || P <= 0 || C <= 0 || KD <= 0 || sd <= 0 || pd < 0 || Do <= 0 || CK < KD * C) return EDRL_EINVAL;
   hipLaunchKernelGGL(depth_fold_kernel, dim3(vgrid((long)N * D * P * C)), dim3(256), 0, st, dy, dx, N, D, Do, P, C, KD, sd, pd,
                      CK);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+// bf16 tensors (C % 8 == 0, CK == KD*C, 16-byte aligned): the depth-unfolded operand / the fold of its gradient for the bf16 3-D trunk
+int edrl_depth_unfold_bf16(const void* x, void* y, int N, int D, long P, int C, int KD, int sd, int pd, int Do, hipStream_t st) {
+  if (N <= 0 || D <= 0 || P <= 0 || C <= 0 || (C & 7) || KD <= 0 || sd <= 0 || pd < 0 || Do <= 0 || !x || !y) return EDRL_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(depth_unfold_h8_kernel, dim3(vgrid((long)N * Do * P * (KD * (C / 8)))), dim3(256), 0, st,
+                     (const unsigned short*)x, (unsigned short*)y, N, D, Do, P, C, KD, sd, pd);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+int edrl_depth_fold_bf16(const void* dy, void* dx, int N, int D, long P, int C, int KD, int sd, int pd, int Do, hipStream_t st) {
+  if (N <= 0 || D <= 0 || P <= 0 || C <= 0 || (C & 7) || KD <= 0 || sd <= 0 || pd < 0 || Do <= 0 || !dy || !dx) return EDRL_EINVAL;
+  if ((((uintptr_t)dy | (uintptr_t)dx) & 15) != 0) return EDRL_EINVAL;
+  hipLaunchKernelGGL(depth_fold_h8_kernel, dim3(vgrid((long)N * D * P * (C / 8))), dim3(256), 0, st, (const unsigned short*)dy,
+                     (unsigned short*)dx, N, D, Do, P, C, KD, sd, pd);
   EDRL_LAUNCH_CHECK();
   return 0;
 }

@@ -1,7 +1,8 @@
 """3-D-conv OCT encoder: the "true 3D" alternative for the `transformer_3DNet` slot
 (fusion_net.py:799,885; the reference's own 3-D networks are MedicalNet ResNets, baseline_models.py:123-178, whose source
 is absent).  Build-owned ResNet3D-10/18 (basic blocks, 7x7x7/s2 stem, MaxPool3d(3,2,1), stride-2 stages with 1x1x1
-"type B" shortcuts), NDHWC fp32, behind the same `(tokens, pooled)` contract as the slice-stack encoder.
+"type B" shortcuts), NDHWC fp32 -- or, with dtype="bf16", bf16 activations / gradients on the bf16 MFMA kernels in the residual
+stages (ConvBn3dBf16Fn; fp32 stem and parameters) -- behind the same `(tokens, pooled)` contract as the slice-stack encoder.
 
 Every 3-D convolution runs as a 2-D implicit-GEMM convolution over the depth-unfolded volume (csrc/vol_ops.hip):
 weights are stored [Co, KH, KW, KD*Ci] (K order of the 2-D MFMA kernel), BatchNorm3d is the 2-D BatchNorm kernels over
@@ -13,7 +14,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .encoders import _bn_fwd, _bn_bwd
+from .encoders import _bn_fwd, _bn_bwd, _conv_bn_fwd_bf16, _bn_bwd_mx
 
 P = L.ptr
 
@@ -98,6 +99,77 @@ class Conv3dFn(torch.autograd.Function):
             dxu = ops.conv2d_dgrad(dy4, ops.permute_weight(w), tuple(xu4.shape), s, p)
             dx = depth_fold(dxu.view(N, Do, H, W, CK), x_shape, KD, sd, pd)
         return dx, dw, None, None, None, None, None
+
+
+def depth_unfold_bf16(x5, KD, sd, pd):
+    N, D, H, W, C = x5.shape
+    Do = (D + 2 * pd - KD) // sd + 1
+    y = torch.empty((N, Do, H, W, KD * C), device=x5.device, dtype=torch.bfloat16)
+    L.call("edrl_depth_unfold_bf16", P(x5), P(y), N, D, H * W, C, KD, sd, pd, Do)
+    return y
+
+
+def depth_fold_bf16(dy5, x_shape, KD, sd, pd):
+    N, D, H, W, C = x_shape
+    dx = torch.empty(x_shape, device=dy5.device, dtype=torch.bfloat16)
+    L.call("edrl_depth_fold_bf16", P(dy5), P(dx), N, D, H * W, C, KD, sd, pd, dy5.shape[1])
+    return dx
+
+
+class ConvBn3dBf16Fn(torch.autograd.Function):
+    """One conv -> BatchNorm3d(train) (-> + residual) (-> ReLU) unit of the bf16 3-D trunk: activations and gradients are bf16
+    tensors, the convolution runs on the bf16 MFMA kernels of the 2-D trunk (fp32 accumulate, BatchNorm statistics from the
+    accumulators) over the depth-unfolded bf16 operand, the weight stays an fp32 parameter [Co,KH,KW,KD*C] and its gradient is fp32.
+    x bf16 [N,D,H,W,C] -> bf16 [N,Do,Ho,Wo,Co]."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, KD, sd, s, pd, p, relu, residual):
+        x = x.contiguous()
+        N, D, H, W, C = x.shape
+        Co, KH, KW, CK = w.shape
+        if CK != KD * C or C % 8 or x.dtype != torch.bfloat16:
+            raise RuntimeError("bf16 3-D unit: bf16 input with C % 8 == 0 and an unpadded [Co,KH,KW,KD*C] weight")
+        xu = x if (KD == 1 and sd == 1) else depth_unfold_bf16(x, KD, sd, pd)
+        Do = xu.shape[1]
+        bn = {"weight": gamma, "bias": beta, "running_mean": running_mean, "running_var": running_var, "momentum": 0.1, "eps": 1e-5}
+        res4 = None
+        if residual is not None:
+            res4 = residual.contiguous().view(N * Do, residual.shape[2], residual.shape[3], Co)
+        raw, out, mean, rstd, mask = _conv_bn_fwd_bf16(xu.view(N * Do, H, W, CK), w, bn, s, p, relu, res4)
+        ctx.save_for_backward(xu, w, raw, mean, rstd, gamma, mask if mask is not None else torch.empty(0, device=x.device))
+        ctx.cfg = (tuple(x.shape), KD, sd, s, pd, p, relu, residual is not None)
+        return out.view(N, Do, out.shape[1], out.shape[2], Co)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xu, w, raw, mean, rstd, gamma, mask = ctx.saved_tensors
+        x_shape, KD, sd, s, pd, p, relu, has_res = ctx.cfg
+        N, D, H, W, C = x_shape
+        Do, CK = xu.shape[1], xu.shape[4]
+        dout4 = dout.contiguous().view(raw.shape)
+        d_raw, dg, db, dres = _bn_bwd_mx(dout4, mask if relu else None, raw, mean, rstd, gamma, has_res)
+        xu4 = xu.view(N * Do, H, W, CK)
+        dw = ops.conv2d_wgrad_bf16(d_raw, xu4, tuple(w.shape), s, p) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxu = ops.conv2d_dgrad_bf16(d_raw, ops.permute_weight_bf16(w), tuple(xu4.shape), s, p)
+            dx = dxu.view(x_shape) if (KD == 1 and sd == 1) else depth_fold_bf16(dxu.view(N, Do, H, W, CK), x_shape, KD, sd, pd)
+        if dres is not None:
+            dres = dres.view(dout.shape)
+        return dx, dw, dg, db, None, None, None, None, None, None, None, None, dres
+
+
+class _CastFn(torch.autograd.Function):
+    """fp32 <-> bf16 boundary of the bf16 3-D trunk (the stem and its max-pool stay fp32, the token projection reads fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, to_bf16):
+        ctx.to_bf16 = to_bf16
+        return ops.to_bf16(x) if to_bf16 else ops.to_f32(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ops.to_f32(g) if ctx.to_bf16 else ops.to_bf16(g)), None
 
 
 class BnActFn(torch.autograd.Function):
@@ -189,6 +261,12 @@ class _Bn3d(nn.Module):
         return BnActFn.apply(raw, self.weight, self.bias, self.running_mean, self.running_var, relu, residual)
 
 
+def _unit_bf16(x, conv, bn, relu, residual):
+    bn.num_batches_tracked += 1
+    return ConvBn3dBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.k, conv.stride,
+                                conv.stride, conv.pad, conv.pad, relu, residual)
+
+
 class _BasicBlock3d(nn.Module):
     def __init__(self, ci, co, stride):
         super().__init__()
@@ -199,6 +277,10 @@ class _BasicBlock3d(nn.Module):
             self.down = nn.ModuleList([_Conv3d(ci, co, 1, stride, 0), _Bn3d(co)])
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16:                        # bf16 trunk (training): fused conv + BatchNorm units on bf16 tensors
+            idn = x if self.down is None else _unit_bf16(x, self.down[0], self.down[1], False, None)
+            o = _unit_bf16(x, self.conv1, self.bn1, True, None)
+            return _unit_bf16(o, self.conv2, self.bn2, True, idn)
         idn = x if self.down is None else self.down[1](self.down[0](x), False)
         o = self.bn1(self.conv1(x), True)
         return self.bn2(self.conv2(o), True, idn)
@@ -207,10 +289,12 @@ class _BasicBlock3d(nn.Module):
 class ResNet3DTrunk(nn.Module):
     """[N,D,H,W,1] -> [N,d,h,w,512] (d = D/16, h = H/32, w = W/32 for sizes divisible by 32)."""
 
-    def __init__(self, depth=18, in_ch=1):
+    def __init__(self, depth=18, in_ch=1, dtype="fp32"):
         super().__init__()
+        assert dtype in ("fp32", "bf16")
         layers = _CFG3D[depth]
         self.depth = depth
+        self.compute_dtype = dtype     # "bf16": the residual stages run on bf16 tensors / the bf16 MFMA kernels in training (fp32 stem, fp32 parameters)
         self.conv1, self.bn1 = _Conv3d(in_ch, 64, 7, 2, 3), _Bn3d(64)
         blocks, ci = [], 64
         for li, (co, n) in enumerate(zip([64, 128, 256, 512], layers)):
@@ -222,17 +306,20 @@ class ResNet3DTrunk(nn.Module):
 
     def forward(self, x):
         x = MaxPool3dFn.apply(self.bn1(self.conv1(x), True))
+        bf16 = self.compute_dtype == "bf16" and self.training and x.is_cuda
+        if bf16:
+            x = _CastFn.apply(x, True)
         for b in self.blocks:
             x = b(x)
-        return x
+        return _CastFn.apply(x, False) if bf16 else x
 
 
 class OCTVolumeEncoder(nn.Module):
     """3-D-conv OCT encoder slot: [B,1,S,H,W] -> (tokens [B, d*h*w, token_dim], pooled [B, token_dim])."""
 
-    def __init__(self, depth=18, token_dim=768):
+    def __init__(self, depth=18, token_dim=768, dtype="fp32"):
         super().__init__()
-        self.trunk = ResNet3DTrunk(depth, in_ch=1)
+        self.trunk = ResNet3DTrunk(depth, in_ch=1, dtype=dtype)
         self.token_proj = nn.Linear(self.trunk.out_channels, token_dim)
 
     def forward(self, x):

@@ -279,9 +279,9 @@ class MedFusion(nn.Module):
         depth = getattr(args, "encoder_depth", 50)
         enc_dtype = getattr(args, "encoder_dtype", "fp32")      # "bf16": bf16 MFMA encoders (C2/C4), fp32 head
         self.transformer_2DNet = FundusEncoder(depth, self.fundus_embedding_dim, enc_dtype)
-        if getattr(args, "oct_encoder", "slices") == "3d":     # true 3-D-conv alternative, fp32
+        if getattr(args, "oct_encoder", "slices") == "3d":     # true 3-D-conv alternative, fp32 or bf16 stages
             from .encoders3d import OCTVolumeEncoder
-            self.transformer_3DNet = OCTVolumeEncoder(getattr(args, "oct3d_depth", 18), self.oct_embedding_dim)
+            self.transformer_3DNet = OCTVolumeEncoder(getattr(args, "oct3d_depth", 18), self.oct_embedding_dim, dtype=enc_dtype)
         else:
             self.transformer_3DNet = OCTSliceEncoder(depth, self.oct_embedding_dim, enc_dtype)
         self.fc_fundus = nn.Sequential(nn.ReLU(), nn.Linear(512, 1024), nn.ReLU())

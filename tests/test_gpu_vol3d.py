@@ -121,3 +121,110 @@ def test_medfusion_step_with_3d_oct_encoder(edrl, dev):
     assert torch.isfinite(out["loss"]) and out["pred"].shape == (2, 2)
     live = [n for n, p in m.named_parameters() if p.grad is not None and n.startswith("transformer_3DNet")]
     assert len(live) == len([n for n, _ in m.transformer_3DNet.named_parameters()])
+
+
+@pytest.mark.parametrize("case", [
+    # N, C, D, H, W, Co, k, stride, pad, relu, residual
+    (2, 64, 4, 12, 12, 64, 3, 1, 1, True, True),
+    (2, 64, 6, 10, 10, 128, 3, 2, 1, True, False),      # stride 2 in all three dims
+    (3, 64, 4, 8, 8, 128, 1, 2, 0, False, False),       # 1x1x1 strided shortcut, no ReLU
+    (1, 128, 3, 14, 14, 128, 3, 1, 1, True, True),
+])
+def test_conv_bn3d_bf16_unit_vs_fp64(edrl, dev, case):
+    """The bf16 3-D unit (ConvBn3dBf16Fn: bf16 MFMA conv over the depth-unfolded bf16 operand -> BatchNorm3d(train) -> + residual ->
+    ReLU) against fp64 on the SAME bf16-rounded inputs and weights: output within one bf16 rounding of the fp64 result plus the
+    rounding of the stored raw tensor; gradients (input, weight, gamma, beta, residual) within the bf16 storage error of d_raw."""
+    from edrl_amd_pkg.encoders3d import ConvBn3dBf16Fn
+    N, C, D, H, W, Co, k, s, p, relu, has_res = case
+    g = torch.Generator().manual_seed(4)
+    xb = torch.randn(N, C, D, H, W, generator=g).bfloat16()
+    w = (torch.randn(Co, C, k, k, k, generator=g) * 0.05)
+    wb = w.bfloat16()
+    gamma, beta = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    xd = xb.double().requires_grad_(True)
+    wd = wb.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    raw = F.conv3d(xd, wd, stride=s, padding=p)
+    rd = None
+    if has_res:
+        rb = torch.randn(raw.shape, generator=g).bfloat16()
+        rd = rb.double().requires_grad_(True)
+    # the kernel stores raw as bf16 and normalises the STORED values with the statistics of the fp32 accumulators: the same here
+    # (rounding as a straight-through step), so that the ReLU decisions are taken on the same numbers up to accumulation order
+    raw_q = raw + (raw.detach().bfloat16().double() - raw.detach())
+    dims = (0, 2, 3, 4)
+    mu = raw.mean(dims, keepdim=True)
+    var = raw.var(dims, unbiased=False, keepdim=True)
+    y = (raw_q - mu) / torch.sqrt(var + 1e-5) * gd.view(1, -1, 1, 1, 1) + bd.view(1, -1, 1, 1, 1)
+    if has_res:
+        y = y + rd
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(gy.double())
+    to5 = lambda t: t.permute(0, 2, 3, 4, 1).contiguous()
+    xh = to5(xb).to(dev).requires_grad_(True)
+    wh = wb.float().permute(0, 3, 4, 2, 1).reshape(Co, k, k, k * C).contiguous().to(dev).requires_grad_(True)     # [Co,KH,KW,(KD,Ci)], bf16-exact values
+    gh, bh = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
+    rh = to5(rb).to(dev).requires_grad_(True) if has_res else None
+    out = ConvBn3dBf16Fn.apply(xh, wh, gh, bh, rm, rv, k, s, s, p, p, relu, rh)
+    assert out.dtype == torch.bfloat16
+    check(f"bf16_unit3d_fwd{case}", out.detach().float().cpu().permute(0, 4, 1, 2, 3), y.detach(), 6e-3)
+    out.backward(to5(gy).to(dev))
+
+    def fro(name, got, ref, tol, tol_max):
+        # relative Frobenius error + the worst entry relative to the largest reference entry (bf16 results: 2^-9 per rounding)
+        e = float((got.double() - ref).norm() / ref.norm())
+        em = float((got.double() - ref).abs().max() / ref.abs().max())
+        print(f"[parity] {name}: rel Frobenius {e:.3e} (tol {tol:.0e}), worst entry {em:.3e} (tol {tol_max:.0e})")
+        assert e < tol and em < tol_max, f"{name}: {e:.3e} / {em:.3e}"
+
+    fro(f"bf16_unit3d_dx{case}", xh.grad.float().cpu().permute(0, 4, 1, 2, 3), xd.grad, 6e-3, 1.2e-2)
+    fro(f"bf16_unit3d_dw{case}", wh.grad.cpu().reshape(Co, k, k, k, C).permute(0, 4, 3, 1, 2), wd.grad, 4e-3, 1e-2)
+    fro(f"bf16_unit3d_dgamma{case}", gh.grad.cpu(), gd.grad, 1e-3, 2e-3)
+    fro(f"bf16_unit3d_dbeta{case}", bh.grad.cpu(), bd.grad, 1e-3, 2e-3)
+    if has_res:
+        fro(f"bf16_unit3d_dres{case}", rh.grad.float().cpu().permute(0, 4, 1, 2, 3), rd.grad, 1e-3, 1e-1)     # (a flipped decision is a whole entry: none expected with the storage-aware reference)
+    bs = raw.detach().transpose(0, 1).reshape(Co, -1)
+    check("bf16_unit3d_running_mean", rm.cpu(), 0.1 * bs.mean(1), 2e-3)
+
+
+def test_resnet3d_trunk_bf16_vs_fp32_trunk(edrl, dev):
+    """ResNet3D-10 with bf16 residual stages against the fp32 trunk with the same parameters: features and parameter gradients
+    agree at bf16 accuracy (relative to the tensor's largest element / by cosine), the pass is finite and bit-reproducible, and
+    eval mode takes the fp32 path."""
+    torch.manual_seed(0)
+    t32 = edrl.ResNet3DTrunk(10).to(dev).train()
+    t16 = edrl.ResNet3DTrunk(10, dtype="bf16").to(dev).train()
+    t16.load_state_dict(t32.state_dict())
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 16, 64, 64, 1, generator=g).to(dev)
+    gy = torch.randn(2, 1, 2, 2, 512, generator=g).to(dev)
+    f32 = t32(x); f32.backward(gy)
+    f16 = t16(x); f16.backward(gy)
+    assert f16.dtype == torch.float32 and bool(torch.isfinite(f16).all())
+    check("trunk3d_bf16_fwd", f16.detach().cpu(), f32.detach().cpu(), 6e-2)
+    worst = 1.0
+    for (n, p32), (_, p16) in zip(t32.named_parameters(), t16.named_parameters()):
+        a, b = p16.grad.flatten().double(), p32.grad.flatten().double()
+        assert bool(torch.isfinite(a).all()), n
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+        worst = min(worst, cos)
+        assert cos > 0.93, f"{n}: cosine {cos:.4f}"      # (batch 2: small-batch BatchNorm amplifies the bf16 noise towards the stem)
+    print(f"[parity] trunk3d bf16 vs fp32: worst gradient cosine {worst:.4f}")
+    assert int(t16.blocks[0].bn1.num_batches_tracked) == 1
+    t16b = edrl.ResNet3DTrunk(10, dtype="bf16").to(dev).train()
+    t16b.load_state_dict(t32.state_dict())          # (t32's running statistics moved once; reset both to the same state)
+    t16c = edrl.ResNet3DTrunk(10, dtype="bf16").to(dev).train()
+    t16c.load_state_dict(t32.state_dict())
+    fb = t16b(x); fb.backward(gy)
+    fc = t16c(x); fc.backward(gy)
+    assert torch.equal(fb, fc)
+    for pb, pc in zip(t16b.parameters(), t16c.parameters()):
+        assert torch.equal(pb.grad, pc.grad)
+    t16.eval()
+    t32.eval()
+    with torch.no_grad():
+        t16.load_state_dict(t32.state_dict())
+        assert torch.equal(t16(x), t32(x))
