@@ -56,15 +56,6 @@ class Conv3dFn(torch.autograd.Function):
             ctx.unfolded = False
             return y
         xu = depth_unfold(x, KD, sd, pd, CK)               # (the 1-channel stem: K = 7 taps padded to 8 columns)
-        ctx.stem = None
-        if (KH, KW, s, p) == (7, 7, 2, 3) and H % 2 == 0 and W % 2 == 0 and CK % 4 == 0 and not ctx.needs_input_grad[0]:
-            # the 7x7x7 / stride-2 stem: its 8 depth columns are the channels of a 2-D 7x7 / stride-2 stem conv, which runs as a
-            # 4x4 / stride-1 conv over the 2x2 space-to-depth image (K = 4*4*32, the vector fast path) like the 2-D trunk's stem
-            y, xs, folded = ops.stem_conv_fwd(xu.view(N * Do, H, W, CK), w, alg_flops=flops)
-            ctx.save_for_backward(xs, w)
-            ctx.stem = (folded, flops)
-            ctx.unfolded = True
-            return y.view(N, Do, y.shape[1], y.shape[2], Co)
         y = ops.conv2d_fwd(xu.view(N * Do, H, W, CK), w, stride=s, pad=p, alg_flops=flops)
         ctx.save_for_backward(xu, w)
         ctx.unfolded = True
@@ -79,9 +70,6 @@ class Conv3dFn(torch.autograd.Function):
         Do, Ho, Wo = dy.shape[1], dy.shape[2], dy.shape[3]
         dy4 = dy.contiguous().view(N * Do, Ho, Wo, Co)
         need_w, need_x = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
-        if getattr(ctx, "stem", None) is not None:          # space-to-depth stem (no input gradient by construction)
-            dw = ops.stem_conv_wgrad(dy4, xs, tuple(w.shape), ctx.stem[0], alg_flops=ctx.stem[1]) if need_w else None
-            return None, dw, None, None, None, None, None
         # depth taps decoded inside the kernels (no unfolded operand, no k_d x wide unfolded gradient + fold pass) where the geometry
         # allows; the unfolded form otherwise (the 1-channel stem, odd depths under a depth stride)
         vol_w = need_w and not ctx.unfolded and bool(L.query("edrl_conv3d_wgrad_ok_f32", N, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW))

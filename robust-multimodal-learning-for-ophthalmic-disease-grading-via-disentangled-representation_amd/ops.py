@@ -204,18 +204,17 @@ def stem_weight_fold(w, inverse=False):
     return out
 
 
-def stem_conv_fwd(x, w, alg_flops=None):
+def stem_conv_fwd(x, w):
     """The 7x7/s2/p3 stem conv.  Even H, W: 4x4/s1 conv on the space-to-depth image (vector MFMA path, K = 64*C/…);
-    -> (y [N,H/2,W/2,Co], the tensor to keep for the weight gradient, folded flag).  `alg_flops`: the caller's algorithmic
-    count when some of the C channels are padding (the 3-D stem: 7 depth taps in 8 columns)."""
+    -> (y [N,H/2,W/2,Co], the tensor to keep for the weight gradient, folded flag)."""
     N, H, W, C = x.shape
     Co = w.shape[0]
     if (H % 2 == 0) and (W % 2 == 0) and tuple(w.shape[1:3]) == (7, 7):
         xs = space_to_depth2(x)
         y = conv2d_fwd(xs, stem_weight_fold(w), stride=1, pad=2, out_hw=(H // 2, W // 2),
-                       alg_flops=alg_flops or 2.0 * N * (H // 2) * (W // 2) * Co * 49 * C)
+                       alg_flops=2.0 * N * (H // 2) * (W // 2) * Co * 49 * C)
         return y, xs, True
-    return conv2d_fwd(x, w, stride=2, pad=3, alg_flops=alg_flops), x, False
+    return conv2d_fwd(x, w, stride=2, pad=3), x, False
 
 
 def stem_conv_fwd_obf16(x, w):
@@ -260,7 +259,7 @@ def stem_conv_fwd_bf16mma(x, w):
     return out, part, chunks, xs, True
 
 
-def stem_conv_wgrad(dy, x_saved, w_shape, folded, alg_flops=None):
+def stem_conv_wgrad(dy, x_saved, w_shape, folded):
     """dy fp32, or bf16 (the bf16 trunk's stem: fp32 x, dy widened on load)."""
     Co, _, _, C = w_shape
     if (folded and _STEM_WGRAD_MMA and dy.dtype == torch.bfloat16 and C == 1 and Co == 64 and x_saved.shape[-1] == 4
@@ -274,10 +273,10 @@ def stem_conv_wgrad(dy, x_saved, w_shape, folded, alg_flops=None):
                       N, Hs, Ws, kernels=2, nbytes=2.0 * dy.numel() + 4.0 * (x_saved.numel() + dw8.numel()))
         return stem_weight_fold(dw8, inverse=True)
     if not folded:
-        return conv2d_wgrad(dy, x_saved, tuple(w_shape), 2, 3, alg_flops=alg_flops)
+        return conv2d_wgrad(dy, x_saved, tuple(w_shape), 2, 3)
     Co, _, _, C = w_shape
     N, Ho, Wo, _ = dy.shape
-    dw8 = conv2d_wgrad(dy, x_saved, (Co, 4, 4, 4 * C), 1, 2, alg_flops=alg_flops or 2.0 * N * Ho * Wo * Co * 49 * C)
+    dw8 = conv2d_wgrad(dy, x_saved, (Co, 4, 4, 4 * C), 1, 2, alg_flops=2.0 * N * Ho * Wo * Co * 49 * C)
     return stem_weight_fold(dw8, inverse=True)
 
 
