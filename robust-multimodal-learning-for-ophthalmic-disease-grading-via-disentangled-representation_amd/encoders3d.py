@@ -9,14 +9,17 @@ weights are stored [Co, KH, KW, KD*Ci] (K order of the 2-D MFMA kernel), BatchNo
 N*D*H*W rows, MaxPool3d is the 2-D max-pool per slice followed by a depth max.  Parity is unpinned by the reference
 (no source); the oracle is torch-CPU F.conv3d / F.batch_norm / F.max_pool3d (oracle/resnet_oracle.py).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .encoders import _bn_fwd, _bn_bwd, _conv_bn_fwd_bf16, _bn_bwd_mx
+from .encoders import _bn_fwd, _bn_bwd, _conv_bn_fwd_bf16, _bn_bwd_mx, _bn_ws, _bcoef_from_partials
 
 P = L.ptr
+_FUSE_STEM3D = os.environ.get("EDRL_FUSE_STEM3D", "1") != "0"     # BatchNorm + ReLU of the 3-D stem folded into its max-pool (training)
 
 
 def depth_unfold(x5, KD, sd, pd, CK):
@@ -225,6 +228,51 @@ class MaxPool3dFn(torch.autograd.Function):
         return dx
 
 
+class StemBnPool3dFn(torch.autograd.Function):
+    """Stem tail of the 3-D trunk in training: BatchNorm3d(train) + ReLU folded into MaxPool3d(3, 2, 1).  The in-plane half of the
+    pool is the 2-D trunk's fused kernel per slice (edrl_maxpool3x3s2_bn_fwd_f32: reads the RAW conv output, applies the single
+    FMA + max per tap, keeps the arg-max byte), the depth half runs on the 4x smaller pooled tensor; backward is gather-form and
+    two-pass like the 2-D stem (statistics of the BatchNorm backward, then d_raw): the activated 64-channel tensor at the stem's
+    resolution and its sign bytes never exist.  raw [N,D,H,W,C] fp32 -> [N,Do,Ho,Wo,C]."""
+
+    @staticmethod
+    def forward(ctx, raw, weight, bias, running_mean, running_var):
+        raw = raw.contiguous()
+        N, D, H, W, C = raw.shape
+        M = N * D * H * W
+        fc = torch.empty((5, C), device=raw.device, dtype=torch.float32)
+        ws, nbytes = _bn_ws(M, C, raw.device)
+        L.call("edrl_bn_train_stats_fcoef_f32", P(raw), M, C, P(weight), P(bias), P(running_mean), P(running_var), 0.1, 1e-5, P(fc),
+               P(ws), nbytes)
+        Ho, Wo, Do = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1, (D + 2 - 3) // 2 + 1
+        p2 = torch.empty((N, D, Ho, Wo, C), device=raw.device, dtype=torch.float32)
+        i2 = torch.empty((N, D, Ho, Wo, C), device=raw.device, dtype=torch.uint8)
+        ops.call_timed_bytes("maxpool_bn_fwd", M * C * 4.0 + p2.numel() * 5.0, "edrl_maxpool3x3s2_bn_fwd_f32", P(raw), P(fc), P(p2), P(i2),
+                             N * D, H, W, C)
+        y = torch.empty((N, Do, Ho, Wo, C), device=raw.device, dtype=torch.float32)
+        i1 = torch.empty((N, Do, Ho, Wo, C), device=raw.device, dtype=torch.uint8)
+        L.call("edrl_maxpool_depth3s2_fwd_f32", P(p2), P(y), P(i1), N, D, Ho * Wo * C)
+        ctx.save_for_backward(raw, fc, i2, i1, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        raw, fc, i2, i1, weight = ctx.saved_tensors
+        N, D, H, W, C = raw.shape
+        M = N * D * H * W
+        Ho, Wo = i2.shape[2], i2.shape[3]
+        d2 = torch.empty((N, D, Ho, Wo, C), device=dy.device, dtype=torch.float32)
+        L.call("edrl_maxpool_depth3s2_bwd_f32", P(dy.contiguous()), P(i1), P(d2), N, D, Ho * Wo * C)
+        ws, nbytes = _bn_ws(M, C, raw.device)
+        ops.call_timed_bytes("maxpool_bn_bwd", M * C * 4.0 + d2.numel() * 5.0, "edrl_maxpool3x3s2_bn_bwd_reduce_f32", P(d2), P(i2), P(raw),
+                             P(fc), P(ws), nbytes, N * D, H, W, C)
+        bc, dg, db = _bcoef_from_partials(ws, (M + 1023) // 1024, 3, M, weight, fc)
+        draw = torch.empty_like(raw)
+        ops.call_timed_bytes("maxpool_bn_bwd", M * C * 8.0 + d2.numel() * 5.0, "edrl_maxpool3x3s2_bn_bwd_apply_f32", P(d2), P(i2), P(raw),
+                             P(fc), P(bc), P(draw), N * D, H, W, C)
+        return draw, dg, db, None, None
+
+
 _CFG3D = {10: [1, 1, 1, 1], 18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
 
 
@@ -305,7 +353,11 @@ class ResNet3DTrunk(nn.Module):
         self.out_channels = 512
 
     def forward(self, x):
-        x = MaxPool3dFn.apply(self.bn1(self.conv1(x), True))
+        if self.training and x.is_cuda and _FUSE_STEM3D:
+            self.bn1.num_batches_tracked += 1
+            x = StemBnPool3dFn.apply(self.conv1(x), self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var)
+        else:
+            x = MaxPool3dFn.apply(self.bn1(self.conv1(x), True))
         bf16 = self.compute_dtype == "bf16" and self.training and x.is_cuda
         if bf16:
             x = _CastFn.apply(x, True)
