@@ -18,7 +18,8 @@ data, y = edrl_amd.synthetic_batch(B, 224, 224, 32, device=dev, seed=1234, rank=
 for _ in range(2):
     edrl_amd.train_step(model, opt, data, y)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     edrl_amd.train_step(model, opt, data, y)
     torch.cuda.synchronize()
 acc = collections.Counter()
@@ -26,7 +27,11 @@ want = ("aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::copy_", 
 for ev in prof.events():
     if ev.name in want:
         st = [s for s in (ev.stack or []) if "_amd/" in s or "bench.py" in s]
-        key = (ev.name, st[0].split("_amd/")[-1] if st else ("autograd engine / " + ((ev.stack or ["?"])[0][-60:])))
+        par = ev.cpu_parent
+        chain = []
+        while par is not None and len(chain) < 3:
+            chain.append(par.name[:48]); par = par.cpu_parent
+        key = (ev.name + " " + str(ev.input_shapes)[:40], st[0].split("_amd/")[-1] if st else ("parents: " + " < ".join(chain)))
         acc[key] += 1
 for (name, where), n in acc.most_common(45):
     print(f"{n:5d}  {name:18s} {where[:150]}")
