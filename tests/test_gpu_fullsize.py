@@ -76,7 +76,7 @@ def _free_gpu():
     torch.cuda.reset_peak_memory_stats()
 
 
-def _full_shape_step(edrl, dev, tag, B, HW, S, enc_dtype="fp32", recompute=False, drop_oct=False, n_runs=2):
+def _full_shape_step(edrl, dev, tag, B, HW, S, enc_dtype="fp32", recompute=False, drop_oct=False, n_runs=2, oct_encoder="slices"):
     """One full optimisation step (fusion_train.py:189-224) at a BASELINE.json shape where the CPU oracle would take minutes.
     Size-independent properties: every loss term and every parameter gradient is finite, the predictions are valid class
     indices, BatchNorm state advanced as the reference's would (2 encoder passes, DILR.bn 4 updates: quirk Q5) and stayed
@@ -86,7 +86,7 @@ def _full_shape_step(edrl, dev, tag, B, HW, S, enc_dtype="fp32", recompute=False
     import types
     _free_gpu()
     args = types.SimpleNamespace(mode="train", batch_size=B, encoder_depth=50, encoder_dtype=enc_dtype,
-                                 activation_recompute=recompute)
+                                 activation_recompute=recompute, oct_encoder=oct_encoder, oct3d_depth=18)
     torch.manual_seed(0)
     model = edrl.MedFusion(2, 2, None, args).to(dev).train()
     state0 = copy.deepcopy(model.state_dict())
@@ -108,7 +108,7 @@ def _full_shape_step(edrl, dev, tag, B, HW, S, enc_dtype="fp32", recompute=False
     assert pred.dtype == torch.int64 and int(pred.min()) >= 0 and int(pred.max()) <= 1
     bad = [n for n, gr in grads.items() if not torch.isfinite(gr).all()]
     assert not bad, f"non-finite gradients: {bad[:5]}"
-    assert len(grads) > 300                                        # both ResNet-50 trunks + the live head
+    assert len(grads) > (300 if oct_encoder == "slices" else 200)   # both ResNet-50 trunks (or ResNet-50 + ResNet3D-18) + the live head
     sd = model.state_dict()
     assert int(sd["DILR.bn1.num_batches_tracked"]) == 4 and int(sd["transformer_3DNet.trunk.bn1.num_batches_tracked"]) == 2
     model.raise_on_nonfinite()                                     # every running mean / variance finite (zero-variance layers too)
@@ -164,3 +164,11 @@ def test_c4_per_gpu_shape_step_oct_dropped_bf16(edrl, dev):
     _, _, peak = _full_shape_step(edrl, dev, "C4 per-GPU (B=4 512x512 128 slices, OCT dropped, bf16)", 4, 512, 128,
                                   enc_dtype="bf16", drop_oct=True)
     assert peak <= 260.0, f"C4 per-GPU peak memory {peak:.1f} GiB"
+
+
+@pytest.mark.parametrize("enc_dtype,B", [("fp32", 32), ("bf16", 64)])
+def test_3d_oct_encoder_full_shape_step_finite_and_deterministic(edrl, dev, enc_dtype, B):
+    """The 3-D-conv OCT encoder at the bench shapes (`bench.py --config C1-3D` / `C2-3D`: ResNet3D-18 on [B,1,32,224,224] beside the
+    ResNet-50 fundus encoder; bf16 = bf16 residual stages on both): depth taps decoded in the kernels (fp32) / bf16 conv + BatchNorm3d
+    units over the unfolded bf16 operand, BatchNorm folded into the stem's max-pool -- same size-independent properties as above."""
+    _full_shape_step(edrl, dev, f"3-D OCT encoder ({enc_dtype}, B={B})", B, 224, 32, enc_dtype=enc_dtype, oct_encoder="3d")
