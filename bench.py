@@ -6,7 +6,9 @@
 
 One "step" = one pass of the hot path over one synthetic batch: zero_grad -> forward(low view) ->
 forward(high view) -> MK_MMD -> backward -> (DP gradient all-reduce) -> Adam.step
-(fusion_train.py:189-224).  Inputs are resident in HBM before the timed region.  Workload at N=1 is
+(fusion_train.py:189-224).  Inputs are resident in HBM before the timed region.  `value` times the product's default execution
+(the two views' encoder passes on two HIP streams); `roofline` / `kernels` come from the `in_order` leg of the same run (the same
+steps with the views one after the other on one stream -- per-kernel HIP-event durations are only meaningful there).  Workload at N=1 is
 BASELINE.json configs[1] (C1): per-GPU batch 32, ResNet-50 encoders, 224x224 fundus + 32-slice OCT, fp32.
 At N>1 it is configs[3] (C3): the same shapes at per-GPU batch 64 (global 512 at N=8), data parallel, with the residual
 blocks' outputs rebuilt in backward so that the fp32 activations of 2 x 64 x 33 images fit one GPU's 288 GB.  The default
@@ -170,7 +172,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of edrl_amd.FusedAdam")
-    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra timed region with the two views overlapped")
+    ap.add_argument("--in-order", action="store_true", help="run the steps in order on one stream (EDRL_VIEW_STREAM=0): `value` is then "
+                    "the in-order rate and there is no separate in-order leg")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="(kept for old command lines) same as --no-in-order-leg")
+    ap.add_argument("--no-in-order-leg", action="store_true", help="skip the in-order leg that carries the per-kernel roofline")
     ap.add_argument("--no-recompute-leg", action="store_true", help="skip the extra timed region with args.activation_recompute")
     ap.add_argument("--no-anchor-leg", action="store_true", help="skip the N = 1 timing of the C3 per-GPU workload (scale_anchor)")
     ap.add_argument("--no-bf16-legs", action="store_true", help="skip the C2 / C4 legs of the default N = 1 line (bf16_leg, c4_leg)")
@@ -258,19 +263,30 @@ def main():
             per_rank = [round(x / steps * 1e3, 3) for x in tl.tolist()]
         return dt, timer, o, per_rank
 
-    def overlap_leg(B, steps):
-        """Not `value`: the same steps with the two views' encoder passes on two HIP streams (edrl_amd.set_view_overlap).  Kernels
-        of the two passes then share the GPU, so per-kernel durations -- and a per-kernel roofline -- stop being meaningful there."""
-        edrl_amd.set_view_overlap(True)
-        step(); torch.cuda.synchronize()
-        dt2, _, _, _ = timed_region(steps, False)
-        edrl_amd.set_view_overlap(False)
-        return {"switch": "EDRL_VIEW_STREAM=1 / edrl_amd.set_view_overlap(True)", "value": round(B * world * steps / dt2, 3),
-                "unit": "images/s", "ms_per_step": round(dt2 / steps * 1e3, 3), "steps": steps,
-                "note": "two views' encoder passes on two HIP streams (MFMA convs of one overlap HBM-bound BatchNorm of the other); "
-                        "identical losses/gradients/running statistics; per-kernel timing not taken in this leg"}
+    # The product default runs the two views' encoder passes on two HIP streams (train.train_step; bit-identical results): that is
+    # what `value` times.  Kernels of the two passes then share the GPU, so per-kernel durations -- and a per-kernel roofline --
+    # are only meaningful with the views in order on ONE stream: the `in_order` leg below runs the same steps that way
+    # (edrl_amd.set_view_overlap(False)) with the HIP-event kernel timer, and `roofline` / `kernels` are taken there.
+    overlapped = (not a.in_order) and edrl_amd.view_overlap()
+    edrl_amd.set_view_overlap(overlapped)
+    want_in_order_leg = overlapped and not (a.no_overlap_leg or a.no_in_order_leg)
 
-    want_overlap = world == 1 and not a.no_overlap_leg and os.environ.get("EDRL_VIEW_STREAM", "0") != "1"
+    def in_order_leg(B, steps, cfg, enc_dtype, desc):
+        """-> (record, roofline, kernels): `steps` in-order steps (one warm-up first) bracketed by HIP events per kernel family."""
+        edrl_amd.set_view_overlap(False)
+        step(); torch.cuda.synchronize()
+        dt2, tm2, _, _ = timed_region(steps, True)
+        edrl_amd.set_view_overlap(True)
+        rec = {"switch": "EDRL_VIEW_STREAM=0 / edrl_amd.set_view_overlap(False) / bench.py --in-order",
+               "value": round(B * world * steps / dt2, 3), "unit": "images/s", "ms_per_step": round(dt2 / steps * 1e3, 3), "steps": steps,
+               "note": "the same steps with the two views one after the other on one stream: identical losses / gradients / running "
+                       "statistics; `roofline` and `kernels` of this line are measured in THIS leg"}
+        roof = kern = None
+        if tm2 is not None:
+            roof, kern = roofline_blocks(tm2, enc_dtype, dt2, steps, cfg, desc)
+            if roof:
+                roof["measured_in"] = "in_order leg of this same run (per-kernel HIP-event durations need the views in order on one stream)"
+        return rec, roof, kern
     c = build(a.config, a.batch)
     B, depth, HW, S, enc_dtype, desc, recompute = c["B"], c["depth"], c["HW"], c["S"], c["enc_dtype"], c["desc"], c["recompute"]
     if rank == 0:
@@ -280,8 +296,10 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] timing {a.steps} step(s)", file=sys.stderr, flush=True)
-    dt, timer, out, per_rank = timed_region(a.steps, True)
-    overlap = overlap_leg(B, a.steps) if want_overlap else None
+    dt, timer, out, per_rank = timed_region(a.steps, not overlapped)
+    in_order = roof_io = kern_io = None
+    if want_in_order_leg:
+        in_order, roof_io, kern_io = in_order_leg(B, min(a.steps, 8), a.config, enc_dtype, desc)
     loss = out["loss"].item()
     model = run["model"]
     model.raise_on_bad_labels()
@@ -332,9 +350,10 @@ def main():
         for t in model.trunks():
             t.recompute_out = False
 
-    def extra_leg(cfg, warm, steps, with_overlap, recompute_=None):
+    def extra_leg(cfg, warm, steps, with_in_order, recompute_=None):
         """Another BASELINE.json configuration on this one GPU, riding in the same JSON line (never `value`): W warm-ups, K timed
-        in-order steps with the HIP-event kernel timer -> its own roofline block; optionally the two-stream view overlap."""
+        steps in the product's default execution, then (with_in_order) K in-order steps with the HIP-event kernel timer -> its own
+        `in_order` record, roofline and kernels blocks."""
         drop()
         cc = build(cfg, recompute=recompute_)
         if rank == 0:
@@ -342,18 +361,19 @@ def main():
         for _ in range(warm):
             step()
         torch.cuda.synchronize()
-        dtl, tml, ol, _ = timed_region(steps, True)
+        dtl, tml, ol, _ = timed_region(steps, not overlapped)
         ll = ol["loss"].item()
         assert ll == ll, f"NaN loss ({cfg} leg)"
         run["model"].raise_on_nonfinite()
         leg = {"config": cc["desc"], "command": f"python bench.py --gpus 1 --config {cfg}", "per_gpu_batch": cc["B"],
                "dtype": cc["enc_dtype"], "value": round(cc["B"] * steps / dtl, 3), "unit": "images/s",
                "ms_per_step": round(dtl / steps * 1e3, 3), "steps": steps, "warmup": warm,
+               "execution": "two views on two HIP streams (product default)" if overlapped else "in order on one stream",
                "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "final_loss": ll}
         if tml is not None:
             leg["roofline"], leg["kernels"] = roofline_blocks(tml, cc["enc_dtype"], dtl, steps, cfg, cc["desc"])
-        if with_overlap:
-            leg["view_overlap"] = overlap_leg(cc["B"], min(steps, 3))
+        if with_in_order and overlapped:
+            leg["in_order"], leg["roofline"], leg["kernels"] = in_order_leg(cc["B"], steps, cfg, cc["enc_dtype"], cc["desc"])
         return leg
 
     # Scale anchor (not `value`): the N > 1 runs of this script use C3 (per-GPU batch 64, block outputs recomputed in backward);
@@ -379,8 +399,8 @@ def main():
     # The bf16 configurations of BASELINE.json in the driver-timed line (never `value`): C2 (configs[2]) and the per-GPU shape of
     # C4 (configs[4]: 512x512 fundus + 128-slice OCT, OCT-dropped second view).
     if default_line and not a.no_bf16_legs:
-        bf16_leg = extra_leg("C2", 2, 5, want_overlap)
-        c4_leg = extra_leg("C4", 1, 3, False)
+        bf16_leg = extra_leg("C2", 2, 5, want_in_order_leg)
+        c4_leg = extra_leg("C4", 1, 3, want_in_order_leg)
         c4_leg["unit"] = "samples/s"
         c4_leg["note"] = "per-GPU shape of the 8-GPU configuration (B=4 per GPU) on one GPU; the 8-rank run is the driver's"
     drop()
@@ -397,12 +417,18 @@ def main():
             "final_loss": loss,
             "peak_mem_GiB": round(peak_primary / 2 ** 30, 2),
         }
+        res["execution"] = ("two views on two HIP streams (product default; bit-identical to the in-order step)" if overlapped
+                            else "in order on one stream (--in-order / EDRL_VIEW_STREAM=0)")
         if timer is not None:
             roof, res["kernels"] = roofline_blocks(timer, enc_dtype, dt, a.steps, a.config, desc)
             if roof:
                 res["roofline"] = roof
-        if overlap is not None:
-            res["view_overlap"] = overlap
+        if in_order is not None:
+            res["in_order"] = in_order
+            if roof_io:
+                res["roofline"] = roof_io
+            if kern_io:
+                res["kernels"] = kern_io
         if recompute_leg is not None:
             res["activation_recompute"] = recompute_leg
         if recompute:

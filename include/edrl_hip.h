@@ -430,6 +430,14 @@ int edrl_adam_chunk_elems(void);
 int edrl_adam_multi_f32(const void* tensors, int n_tensors, const void* chunks, int n_chunks, double lr, double beta1,
                         double beta2, double eps, double weight_decay, long step, hipStream_t stream);
 
+/* Weight shadows of a whole encoder trunk in one launch: for every conv weight w fp32 [A][B][C] (= [Co][KH*KW][Ci]) the bf16
+ * forward operand `cast` (same layout; NULL for the fp32 trunk) and the data-gradient operand `perm` [C][B][A] (bf16 when
+ * perm_bf16 != 0, else fp32; NULL to skip) -- the values of edrl_cast_f32_to_bf16 / edrl_permute_weight_{f32,bf16}.  The host
+ * (encoders.ResNetTrunk.build_shadows, called once per train_step before the first view) replaces one cast + one permute launch per
+ * layer and view with this.  tensors: device array of {const float* w; void* cast; void* perm; int A, B, C, perm_bf16; long n}
+ * records (48 bytes); chunks as for edrl_adam_multi_f32. */
+int edrl_weight_shadows_multi(const void* tensors, int n_tensors, const void* chunks, int n_chunks, hipStream_t stream);
+
 /* 3-D convolution forward over NDHWC volumes without the depth-unfolded copy (the true-3-D OCT encoder of SURVEY.md section 8f row 4;
  * layer shapes of the reference's 3-D networks, baseline_models.py:154-178): x [N,Di,Hi,Wi,Ci], w [Co,KH,KW,KD*Ci] (the
  * depth-unfolded weight layout, depth tap innermost of the taps), y [N,Do,Ho,Wo,Co]; depth stride / padding dstride / dpad,
@@ -453,9 +461,11 @@ int edrl_conv3d_ndhwc_dgrad_f32(const float* dy, const float* wt3, float* dx, in
 
 /* 3-D convolution weight gradient over NDHWC volumes without the depth-unfolded operand (same row): dy [N,Do,Ho,Wo,Co],
  * x [N,Di,Hi,Wi,Ci] -> dw [Co,KH,KW,KD*Ci] (the depth-unfolded weight layout).  Workspace =
- * edrl_conv2d_nhwc_wgrad_workspace_bytes(N*Do, Ho, Wo, Co, KD*Ci, KH, KW).  Ci % 4 == 0, Co % 4 == 0, dense 16-byte aligned tensors,
+ * edrl_conv3d_wgrad_workspace_bytes(N, Do, Ho, Wo, Co, Ci, KD, KH, KW) (the launcher's own split-K plan).  Ci % 4 == 0, Co % 4 == 0,
+ * dense 16-byte aligned tensors,
  * buffer-load path geometry: edrl_conv3d_wgrad_ok_f32; callers fall back to edrl_depth_unfold_f32 + edrl_conv2d_nhwc_wgrad_f32. */
 int edrl_conv3d_wgrad_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW);
+size_t edrl_conv3d_wgrad_workspace_bytes(int N, int Do, int Ho, int Wo, int Co, int Ci, int KD, int KH, int KW);
 int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int N, int Di,
                                 int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW, int dstride,
                                 int stride, int dpad, int pad, int accumulate, hipStream_t stream);
@@ -465,15 +475,28 @@ int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, floa
  * partial quantum (workgroup count just above a multiple of 256, or at most 128 in all) are K-split (csrc/conv_gemm.hip
  * gather_ksplit_plan, switch EDRL_GATHER_TAIL_SPLIT); bench.py reads the difference around a call so that its launch count equals
  * rocprofv3's.
- * Library-owned device memory: the K-split keeps one 16 MiB slab per stream the family is launched on (hipMalloc at the first
- * split call on that stream, at most 8 streams, never freed; a failed allocation just disables the split).  Every other
- * workspace of this ABI is the caller's. */
+ * The library allocates nothing: the slab the split workgroups hand their accumulators over in is the caller's, see below. */
 long edrl_gather_launch_count(void);
+
+/* K-split workspace of the fp32 gather family (csrc/conv_gemm.hip gather_ksplit_plan).  The caller registers ONE slab of at least
+ * edrl_gather_ksplit_workspace_bytes() (16 MiB, 16-byte aligned) per (current HIP device, stream) it launches the family on; the
+ * library keeps only the (device, stream) -> pointer table (64 entries: -28 when full) and never allocates or frees.  slab NULL
+ * forgets the entry.  A launch on a (device, stream) without a registered slab runs unsplit: same body tiles bit for bit, tail
+ * tiles differ by the association of the K sum -- register before the first launch if run-to-run identity across streams matters
+ * (<package>/_lib.py does, from the torch caching allocator, the first time a stream issues a library call).  The slab must stay
+ * valid until the stream's last gather launch has completed or the entry is replaced. */
+size_t edrl_gather_ksplit_workspace_bytes(void);
+int edrl_gather_ksplit_set_workspace(float* slab, size_t bytes, hipStream_t stream);
 
 /* Run-time switches (EDRL_* environment variables, csrc/edrl_config.h) are read ONCE at first use; this re-reads them.  For tests
  * and A/B scripts, between launches (not while other threads launch).  Returns 1 if the library was built with -DEDRL_DIAG
  * (diagnostic kernel variants present: libedrl_hip_diag.so), 0 for the shipped library. */
 int edrl_config_reload(void);
+
+/* Measurement aid: an empty one-wave dispatch (kernel `edrl_trace_mark_kernel`).  The host-side call tracer
+ * (<package>/_lib.py trace_begin / trace_end, scripts/step_trace.py) issues one in front of every library call so that a rocprofv3
+ * kernel trace or --pmc pass of a whole training step can be attributed call by call (layer by layer) from dispatch order alone. */
+int edrl_trace_mark(hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -339,9 +339,71 @@ def gen_eval(ref, tag, B, seed):
     print(f"wrote head_eval_{tag}.npz (loss {loss.item():.6f})")
 
 
+def gen_salt_pepper():
+    """`add_salt_peper` / `add_salt_peper_3D` (code/data_harvard.py:24-48).  data_harvard.py cannot be
+    imported here (cv2, nibabel, torchvision absent), but these two helpers are numpy-only: their FunctionDef nodes are taken
+    from the file's syntax tree and compiled on their own (nothing else of the module runs), with `np.random.randint` wrapped so
+    that the coordinate draws are recorded.  Stored: inputs, the reference's outputs, and the draws in call order."""
+    import ast
+    src = open(os.path.join(REF, "code", "data_harvard.py")).read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("add_salt_peper", "add_salt_peper_3D")]
+    assert sorted(f.name for f in fns) == ["add_salt_peper", "add_salt_peper_3D"]
+    draws = []
+
+    class _Random:
+        def randint(self, lo, hi, n):
+            r = np.random.randint(lo, hi, n)
+            draws.append(np.asarray(r, dtype=np.int64))
+            return r
+
+    class _NP:                       # numpy, except that random.randint records what it returns
+        random = _Random()
+
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+    ns = {"np": _NP()}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "data_harvard_salt_pepper", "exec"), ns)
+    out = {}
+    # 2-D (fundus) form: HWC image, every channel of a drawn pixel set; the loader calls it on CHW.transpose(1, 2, 0)
+    for tag, (H, W, C, amount, seed) in {"hwc_a": (37, 41, 3, 0.05, 11), "hwc_b": (64, 48, 3, 0.2, 12), "hwc_c": (9, 7, 3, 0.5, 13)}.items():
+        rng = np.random.RandomState(seed)
+        x = rng.rand(H, W, C).astype(np.float32)
+        np.random.seed(seed + 100)
+        del draws[:]
+        y = ns["add_salt_peper"](x, amount)
+        assert len(draws) == 6                      # (rows, cols, channel draw that the function ignores) x (salt, pepper)
+        out.update({f"{tag}_x": x, f"{tag}_y": y.astype(np.float32), f"{tag}_amount": amount,
+                    f"{tag}_salt_r": draws[0], f"{tag}_salt_c": draws[1], f"{tag}_pep_r": draws[3], f"{tag}_pep_c": draws[4]})
+    # 3-D (OCT) form: the loader calls it per slice kk[i, :, :] (data_harvard.py:322-323) -> a 2-D [H, W] image
+    for tag, (S, H, W, amount, seed) in {"oct_a": (4, 24, 20, 0.1, 21), "oct_b": (3, 16, 16, 0.02, 22)}.items():
+        rng = np.random.RandomState(seed)
+        x = rng.rand(S, H, W).astype(np.float32)
+        np.random.seed(seed + 100)
+        y = np.empty_like(x)
+        sr, sc, pr, pc = [], [], [], []
+        for i in range(S):
+            del draws[:]
+            y[i] = ns["add_salt_peper_3D"](x[i], amount)
+            assert len(draws) == 4
+            sr.append(draws[0]); sc.append(draws[1]); pr.append(draws[2]); pc.append(draws[3])
+        out.update({f"{tag}_x": x, f"{tag}_y": y, f"{tag}_amount": amount, f"{tag}_salt_r": np.stack(sr), f"{tag}_salt_c": np.stack(sc),
+                    f"{tag}_pep_r": np.stack(pr), f"{tag}_pep_c": np.stack(pc)})
+    # the restatement the CPU suite checks against this fixture
+    from oracle import data_oracle as D
+    for tag in ("hwc_a", "hwc_b", "hwc_c"):
+        assert np.array_equal(D.salt_pepper_hwc(out[f"{tag}_x"], out[f"{tag}_salt_r"], out[f"{tag}_salt_c"], out[f"{tag}_pep_r"],
+                                                out[f"{tag}_pep_c"]), out[f"{tag}_y"]), tag
+        assert len(out[f"{tag}_salt_r"]) == D.salt_pepper_count(out[f"{tag}_amount"], *out[f"{tag}_x"].shape[:2])
+    np.savez_compressed(os.path.join(OUT, "salt_pepper.npz"), **out)
+    print("wrote salt_pepper.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    gen_salt_pepper()
     ref, ref_mmd = import_reference()
     gen_mmd(ref_mmd)
     gen_divergences(ref_mmd)

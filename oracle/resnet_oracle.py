@@ -95,18 +95,22 @@ def conv_bn_bf16_op(x, w, gamma, beta, stride, pad, relu, residual=None):
     return raw, _q16(y), mean.flatten(), var.flatten()
 
 
-def trunk_forward_bf16(x, sd, kind, blocks):
+def trunk_forward_bf16(x, sd, kind, blocks, stem_q16=False):
     """Storage-aware restatement of the product's bf16 trunk (encoders._TrunkBf16Fn, SURVEY.md §8a rows E1/E2 at
     C2/C4): same topology as trunk_forward, with a bf16 rounding at exactly the tensors the product stores in bf16
     (conv_bn_bf16_op).  The stem conv (fp32 image and weights in the product) and all BatchNorm arithmetic stay in the working
     precision; the stem's raw output is stored as bf16 like every other layer's (statistics from the unrounded values, as the
     product takes them from the fp32 accumulators).  Training-mode batch statistics only (running statistics are not touched).
-    Autograd sees straight-through roundings."""
+    Autograd sees straight-through roundings.  stem_q16: the 1-channel (OCT) stem of the product runs on the bf16 matrix pipe
+    (encoders._KBF16.stem_fwd, EDRL_BF16_STEM_MMA): image and stem weights are rounded to bf16 on the way into the MFMA."""
     def cb(x, cname, bname, stride, pad, relu, residual=None):
         return conv_bn_bf16_op(x, sd[cname + ".weight"], sd[bname + ".weight"], sd[bname + ".bias"], stride, pad, relu,
                                residual)[1]
 
-    a = _conv(x, sd, "conv1", 2, 3)
+    if stem_q16:
+        a = F.conv2d(_q16(x), _q16(sd["conv1.weight"]).permute(0, 3, 1, 2)[:, :x.shape[1]], stride=2, padding=3)
+    else:
+        a = _conv(x, sd, "conv1", 2, 3)
     mean = a.mean(dim=(0, 2, 3), keepdim=True)
     var = a.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
     a = (_q16(a) - mean) * torch.rsqrt(var + 1e-5) * sd["bn1.weight"].view(1, -1, 1, 1) + sd["bn1.bias"].view(1, -1, 1, 1)

@@ -12,8 +12,12 @@ from . import resnet_oracle as RO
 
 
 class OracleEDRL:
-    def __init__(self, product_model, dtype=torch.float32):
+    def __init__(self, product_model, dtype=torch.float32, encoder_storage="fp32"):
+        """encoder_storage="bf16": the encoders follow the product's bf16 trunk (C2 / C4) -- resnet_oracle.trunk_forward_bf16, a
+        bf16 rounding at exactly the tensors the product stores in bf16, straight-through for autograd -- in the working precision
+        `dtype`; token adapters and head as in the fp32 configuration (the product computes them in fp32)."""
         self.dtype = dtype
+        self.encoder_storage = encoder_storage
         self.batch_size = product_model.args.batch_size
         self.enc = {}
         for key in ("transformer_2DNet", "transformer_3DNet"):
@@ -48,6 +52,18 @@ class OracleEDRL:
         (resnet_oracle.pins_from_capture), which take the ill-conditioned sign bits out of a gradient comparison."""
         f, o = self.enc["transformer_2DNet"], self.enc["transformer_3DNet"]
         pf, po = pins if pins is not None else (None, None)
+        if self.encoder_storage == "bf16":
+            assert pins is None, "decision pins are an fp32-trunk tool"
+            import torch.nn.functional as F
+            ff = RO.trunk_forward_bf16(X[0].to(self.dtype), f["sd"], f["kind"], f["blocks"])
+            Bn, C, h, w = ff.shape
+            x = F.linear(ff.permute(0, 2, 3, 1).reshape(Bn, h * w, C), f["w"], f["b"])
+            xo = X[1].to(self.dtype)
+            Bn, _, S, H, W = xo.shape
+            fo = RO.trunk_forward_bf16(xo.reshape(Bn * S, 1, H, W), o["sd"], o["kind"], o["blocks"],
+                                       stem_q16=(H % 2 == 0 and W % 2 == 0))     # even sizes take the bf16-MFMA stem
+            x1 = F.linear(fo.mean(dim=(2, 3)).reshape(Bn, S, -1), o["w"], o["b"])
+            return O.medfusion_forward_tokens(self.p, self.state, x, x1, y, noise, self.batch_size)
         x, _ = RO.fundus_encoder_forward(X[0].to(self.dtype), f["sd"], f["kind"], f["blocks"], f["w"], f["b"], pins=pf)
         x1, _ = RO.oct_encoder_forward(X[1].to(self.dtype), o["sd"], o["kind"], o["blocks"], o["w"], o["b"], pins=po)
         return O.medfusion_forward_tokens(self.p, self.state, x, x1, y, noise, self.batch_size)

@@ -13,11 +13,11 @@ from .mmd import MK_MMD, compute_js_divergence, compute_kl_divergence
 from .medfusion import MedFusion, EPRL, PoE, DILR, AttentionModel, off_diagonal
 from .encoders import ResNetTrunk, FundusEncoder, OCTSliceEncoder
 from .encoders3d import ResNet3DTrunk, OCTVolumeEncoder
-from .train import train_step, train, val, synthetic_batch, device_twin_views, set_view_overlap, DevicePrefetcher
+from .train import train_step, train, val, synthetic_batch, device_twin_views, set_view_overlap, view_overlap, DevicePrefetcher
 from . import dist
 from .dist import GradSync, broadcast_parameters
 from .optim import FusedAdam
 
 __all__ = ["MedFusion", "EPRL", "PoE", "DILR", "AttentionModel", "off_diagonal", "MK_MMD", "compute_js_divergence", "compute_kl_divergence", "ResNetTrunk",
-           "FundusEncoder", "OCTSliceEncoder", "ResNet3DTrunk", "OCTVolumeEncoder", "train_step", "train", "val", "synthetic_batch", "device_twin_views", "set_view_overlap", "DevicePrefetcher", "ops", "GradSync",
+           "FundusEncoder", "OCTSliceEncoder", "ResNet3DTrunk", "OCTVolumeEncoder", "train_step", "train", "val", "synthetic_batch", "device_twin_views", "set_view_overlap", "view_overlap", "DevicePrefetcher", "ops", "GradSync",
            "broadcast_parameters", "FusedAdam"]

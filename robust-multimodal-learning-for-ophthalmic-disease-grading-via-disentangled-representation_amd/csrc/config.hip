@@ -1,5 +1,6 @@
 // The library's run-time switches (edrl_config.h): one read of the environment, re-read on request.
 #include "edrl_config.h"
+#include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <mutex>
 
@@ -52,4 +53,14 @@ extern "C" int edrl_config_reload(void) {
 #else
   return 0;
 #endif
+}
+
+// C-ABI (include/edrl_hip.h): an empty one-wave dispatch.  The call tracer (_lib.call with tracing on, scripts/step_trace.py)
+// issues one in front of every library call, so that the dispatches of a rocprofv3 kernel trace / --pmc pass can be cut into
+// calls by position: the k-th `edrl_trace_mark_kernel` row precedes the kernels of the k-th logged call.  Reads and writes nothing.
+__global__ void edrl_trace_mark_kernel() {}
+extern "C" int edrl_trace_mark(hipStream_t stream) {
+  hipLaunchKernelGGL(edrl_trace_mark_kernel, dim3(1), dim3(64), 0, stream);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
 }

@@ -20,6 +20,7 @@
 // Global->LDS is register staged and double buffered (one barrier per K tile):
 // tile t+1's loads are issued before tile t's MFMAs and written after them.
 #include "edrl_common.h"
+#include <atomic>
 #include <mutex>
 #include "edrl_config.h"
 #include <type_traits>
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 // kernels of the gather family issued by this process (edrl_gather_launch_count): a call may issue several (parity classes of a
 // strided data gradient, body + tail of a split call); the bench's timer reads the difference around a call so that its launch
 // count is the one rocprofv3 sees
-static long g_gather_launches = 0;
+static std::atomic<long> g_gather_launches{0};      // (launchers run on autograd worker threads as well as the main thread)
 
 template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
           bool OUT16 = false, bool VOL = false>
@@ -1038,22 +1039,25 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
 // Deterministic; not bit-identical to the unsplit kernel on the tail tiles (the K sum is associated differently).
 // Measured and dropped on the way: the tail as 128 x 64 tiles in a second launch (+1..2 % only: the body's ragged end and the
 // launch boundary eat the gain; the narrow tile itself is 8-10 % slower).
-static hipStream_t g_slab_stream[8];
-static float* g_slab_ptr[8];
-static int g_slab_n = 0;
+// The slab the split workgroups leave their accumulators in is CALLER-OWNED (kernels never allocate): the
+// host wrapper registers one per (device, stream) it launches the family on -- edrl_gather_ksplit_set_workspace, memory from the
+// torch caching allocator (<package>/_lib.py) -- and the library only keeps the table.  No slab registered for a launch's (device,
+// stream): no split (the unsplit kernel, bit-identical on the body tiles).  Launches of one stream are ordered, so one slab per
+// stream suffices; g_slab_mutex additionally spans the main + fix-up launch pair, so two host threads that issue split calls on
+// one stream cannot interleave their halves.
 static const size_t GATHER_SLAB_BYTES = (size_t)256 * 128 * 128 * sizeof(float);     // 256 split workgroups x one 128 x 128 tile
+static const int GATHER_SLAB_MAX = 64;
+static struct { int dev; hipStream_t stream; float* ptr; } g_slab[GATHER_SLAB_MAX];
+static int g_slab_n = 0;
 static std::mutex g_slab_mutex;
-static float* gather_slab(hipStream_t st) {      // one slab per stream the family is launched on (launches of a stream are ordered)
-  std::lock_guard<std::mutex> lock(g_slab_mutex);
+static float* gather_slab_locked(hipStream_t st) {      // g_slab_mutex held
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   for (int i = 0; i < g_slab_n; ++i)
-    if (g_slab_stream[i] == st) return g_slab_ptr[i];
-  if (g_slab_n >= 8) return nullptr;
-  void* p = nullptr;
-  if (hipMalloc(&p, GATHER_SLAB_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  g_slab_stream[g_slab_n] = st; g_slab_ptr[g_slab_n] = (float*)p;
-  return g_slab_ptr[g_slab_n++];
+    if (g_slab[i].dev == dev && g_slab[i].stream == st) return g_slab[i].ptr;
+  return nullptr;
 }
-static bool gather_ksplit_plan(const GatherGeom& g, hipStream_t st, GatherSplit* S, int bn) {
+static bool gather_ksplit_plan(const GatherGeom& g, GatherSplit* S, int bn) {
   if (!edrl_cfg().gather_tail_split) return false;
   const int tiles_m = edrl_cdiv(g.M, 128), tiles_n = edrl_cdiv(g.NC, bn);
   if (tiles_n <= 0 || tiles_n > 256 || (256 % tiles_n)) return false;
@@ -1068,9 +1072,7 @@ static bool gather_ksplit_plan(const GatherGeom& g, hipStream_t st, GatherSplit*
   if (ks < 2) return false;
   // worth it only when the saved part of a tile time ((1 - 1/ks) x ~61 ns per K element, measured) exceeds the fix-up launch (~30 us)
   if ((long)g.Ktot * (ks - 1) / ks < 640) return false;
-  float* slab = gather_slab(st);
-  if (!slab) return false;
-  S->mode = 1; S->n_body = body * tiles_n; S->ksplit = ks; S->kt_per = edrl_cdiv(KT, ks); S->slab = slab;
+  S->mode = 1; S->n_body = body * tiles_n; S->ksplit = ks; S->kt_per = edrl_cdiv(KT, ks); S->slab = nullptr;
   return true;
 }
 
@@ -1079,7 +1081,11 @@ template <int BN, bool DGRAD, int OCC, int ATR = 0, int EPI = 0, bool MASK = tru
 static int launch_gather_split(const float* src, const float* wm, float* dst, const float* bias, const float* mul,
                                const GatherGeom& g, hipStream_t st, const GatherFuse* fuse = nullptr) {
   GatherSplit S;
-  if (!gather_ksplit_plan(g, st, &S, BN))
+  if (!gather_ksplit_plan(g, &S, BN))
+    return launch_gather_v2<128, BN, DGRAD, 16, OCC, true, true, ATR, EPI, MASK>(src, wm, dst, bias, mul, g, st, fuse);
+  std::lock_guard<std::mutex> lock(g_slab_mutex);       // held across the launch pair
+  S.slab = gather_slab_locked(st);
+  if (!S.slab)
     return launch_gather_v2<128, BN, DGRAD, 16, OCC, true, true, ATR, EPI, MASK>(src, wm, dst, bias, mul, g, st, fuse);
   for (int mode = 1; mode <= 2; ++mode) {
     S.mode = mode;
@@ -1775,7 +1781,27 @@ __global__ void permute_021_kernel(const float* __restrict__ in, float* __restri
 extern "C" {
 
 // Kernels of the fp32 implicit-GEMM gather family launched by this process so far (diagnostic: bench.py's per-launch averages).
-long edrl_gather_launch_count(void) { return g_gather_launches; }
+long edrl_gather_launch_count(void) { return g_gather_launches.load(); }
+// K-split slab of the fp32 gather family: caller-owned, registered per (current device, stream); see gather_slab_locked above.
+size_t edrl_gather_ksplit_workspace_bytes(void) { return GATHER_SLAB_BYTES; }
+int edrl_gather_ksplit_set_workspace(float* slab, size_t bytes, hipStream_t st) {
+  if (slab && bytes < GATHER_SLAB_BYTES) return EDRL_ENOSPC;
+  if (slab && ((uintptr_t)slab & 15)) return EDRL_EINVAL;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  std::lock_guard<std::mutex> lock(g_slab_mutex);
+  for (int i = 0; i < g_slab_n; ++i)
+    if (g_slab[i].dev == dev && g_slab[i].stream == st) {
+      if (slab) { g_slab[i].ptr = slab; return 0; }
+      g_slab[i] = g_slab[--g_slab_n];                   // NULL: forget this (device, stream)
+      return 0;
+    }
+  if (!slab) return 0;
+  if (g_slab_n >= GATHER_SLAB_MAX) return EDRL_ENOSPC;
+  g_slab[g_slab_n].dev = dev; g_slab[g_slab_n].stream = st; g_slab[g_slab_n].ptr = slab;
+  ++g_slab_n;
+  return 0;
+}
 
 // Convolution forward on NHWC fp32 (also any Linear: KH=KW=1, H=W=1, N=rows).
 // y[n,ho,wo,co] = act( sum x[n,ho*s-p+kh,wo*s-p+kw,ci] * w[co,kh,kw,ci] + bias[co] ) * mul + (accum ? y : 0)
@@ -2121,6 +2147,15 @@ int edrl_conv3d_wgrad_ok_f32(int N, int Di, int Hi, int Wi, int Ci, int Do, int 
   const long span = (long)tps * WG_BK;
   return (WG_BK / Wo + 1 <= Ho) && span * Co * 4 < (1L << 31) &&
          (span / ((long)Do * Ho * Wo) + 2) * Di * Hi * Wi * Ci * 4 < (1L << 31);
+}
+// Workspace of edrl_conv3d_ndhwc_wgrad_f32: the launcher's own split-K plan (tap count KD*KH*KW; the 2-D helper called with
+// KD*Ci channels plans with KH*KW taps and can come out smaller for KD > 1 with KH = KW = 1).
+size_t edrl_conv3d_wgrad_workspace_bytes(int N, int Do, int Ho, int Wo, int Co, int Ci, int KD, int KH, int KW) {
+  if (N <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || Ci <= 0 || KD <= 0 || KH <= 0 || KW <= 0) return 0;
+  int bm, bn, splits, tps;
+  const long K = (long)KD * KH * KW * Ci;
+  wgrad_plan((long)N * Do * Ho * Wo, Co, (int)K, KD * KH * KW, &bm, &bn, &splits, &tps);
+  return (size_t)splits * Co * K * sizeof(float);
 }
 int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, float* workspace, size_t workspace_bytes, int N, int Di,
                                 int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co, int KD, int KH, int KW, int dstride,

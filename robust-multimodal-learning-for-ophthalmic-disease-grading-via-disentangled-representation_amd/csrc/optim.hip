@@ -58,9 +58,49 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTensor* __res
   }
 }
 
+// Weight shadows of a whole trunk in ONE launch (round 5; replaces one cast + one permute launch per conv layer, view and step):
+// for every conv weight w fp32 [A][B][C] (= [Co][KH*KW][Ci]) the forward operand `cast` (same layout, bf16: bf16 trunk only) and
+// the data-gradient operand `perm` [C][B][A] (= [Ci][KH*KW][Co]; bf16 or fp32).  Same table + chunk scheme as the Adam kernel;
+// the values are exactly those of edrl_cast_f32_to_bf16 / edrl_permute_weight_{f32,bf16} (one rounding of the fp32 weight).
+struct ShadowTensor {
+  const float* w;
+  void* cast;        // bf16 [A][B][C], or NULL
+  void* perm;        // [C][B][A] bf16 (perm_bf16 != 0) or fp32, or NULL
+  int A, B, C, perm_bf16;
+  long n;
+};
+__global__ __launch_bounds__(256) void weight_shadow_multi_kernel(const ShadowTensor* __restrict__ tab, const AdamChunk* __restrict__ chunks) {
+  const AdamChunk c = chunks[blockIdx.x];
+  const ShadowTensor t = tab[c.tensor];
+  const long base = (long)c.chunk * ADAM_CHUNK;
+  long end = base + ADAM_CHUNK; if (end > t.n) end = t.n;
+  __bf16* cast = (__bf16*)t.cast;
+  const long BC = (long)t.B * t.C;
+  for (long i = base + threadIdx.x; i < end; i += 256) {
+    const float v = t.w[i];
+    if (cast) cast[i] = (__bf16)v;
+    if (t.perm) {
+      const int a = (int)(i / BC);
+      const long r = i - (long)a * BC;
+      const int b = (int)(r / t.C), cc = (int)(r - (long)b * t.C);
+      const long o = ((long)cc * t.B + b) * t.A + a;
+      if (t.perm_bf16) ((__bf16*)t.perm)[o] = (__bf16)v; else ((float*)t.perm)[o] = v;
+    }
+  }
+}
+
 extern "C" {
 
 int edrl_adam_chunk_elems(void) { return ADAM_CHUNK; }
+
+// tensors: device array of n_tensors records {const float* w; void* cast; void* perm; int A, B, C, perm_bf16; long n} (48 bytes
+// each, n = A*B*C); chunks: device array of {int tensor; int chunk} records covering every tensor in edrl_adam_chunk_elems() pieces.
+int edrl_weight_shadows_multi(const void* tensors, int n_tensors, const void* chunks, int n_chunks, hipStream_t st) {
+  if (n_tensors <= 0 || n_chunks <= 0 || tensors == nullptr || chunks == nullptr) return EDRL_EINVAL;
+  hipLaunchKernelGGL(weight_shadow_multi_kernel, dim3(n_chunks), dim3(256), 0, st, (const ShadowTensor*)tensors, (const AdamChunk*)chunks);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
 
 // tensors: device array of n_tensors records {float* p; const float* g; float* m; float* v; long n} (40 bytes each);
 // chunks: device array of n_chunks records {int tensor; int chunk} covering every tensor in ADAM_CHUNK-element pieces.

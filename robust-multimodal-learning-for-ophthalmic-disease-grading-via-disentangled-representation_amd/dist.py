@@ -80,10 +80,21 @@ class GradSync:
                 p.grad = v                                   # autograd accumulates into the bucket in place
             self.buckets.append({"params": ps, "flat": flat, "views": views, "ready": 0, "launched": False, "handle": None,
                                  "seen": [False] * len(ps)})
+        # share of each bucket's elements that are encoder-trunk parameters (diagnostics: which launches carry encoder gradients)
+        names = {p: n for n, p in model.named_parameters()} if hasattr(model, "named_parameters") else {}
+        for bi, b in enumerate(self.buckets):
+            b["index"] = bi
+            enc = sum(p.numel() for p in b["params"] if ".trunk." in names.get(p, ""))
+            b["encoder_fraction"] = enc / max(b["flat"].numel(), 1)
         if self.params and self.params[0].is_cuda:
             self.comm_stream = torch.cuda.Stream()
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        # The encoder trunks sum the two views' parameter gradients themselves, stage by stage, straight into the bucket views
+        # (encoders._TrunkFn.backward: no autograd hook fires for them inside a train_step) and report every finished residual
+        # stage here -- so encoder buckets go out during backward, not after the last trunk node has returned.
+        for t in (model.trunks() if hasattr(model, "trunks") else ()):
+            t.grad_sink = self.params_ready
 
     # ---- step protocol: zero_grad() -> forward/backward (hooks launch full buckets) -> finish() -> optimizer.step()
     def zero_grad(self):
@@ -128,6 +139,12 @@ class GradSync:
         if b["ready"] >= len(b["params"]):
             self._launch(b)
 
+    def params_ready(self, params):
+        """The `.grad` of these parameters is complete for this step (the encoder trunks call this per residual stage)."""
+        for p in params:
+            if p in self.index:
+                self._on_grad(p)
+
     # ---- diagnostics ------------------------------------------------------------------------------------------------------
     def enable_diagnostics(self, on=True):
         """Record, per step: when backward started / ended and when each bucket's all-reduce was ISSUED (host clock and an
@@ -154,13 +171,15 @@ class GradSync:
         (t0, e0), (t1, e1) = d["bwd"]
         rep = {"buckets": len(self.buckets), "bytes_exchanged": self.total_bytes(), "collectives_this_step": len(d["launch"]),
                "backward_host_ms": round((t1 - t0) * 1e3, 3),
-               "launch_host_ms_after_backward_start": [round((t - t0) * 1e3, 3) for t, _, _ in d["launch"]],
-               "launched_in_finish": [bool(f) for _, _, f in d["launch"]]}
+               "launch_host_ms_after_backward_start": [round((t - t0) * 1e3, 3) for t, _, _, _ in d["launch"]],
+               "launched_in_finish": [bool(f) for _, _, f, _ in d["launch"]],
+               "launch_bucket_index": [bi for _, _, _, bi in d["launch"]],
+               "launch_encoder_fraction": [round(self.buckets[bi]["encoder_fraction"], 3) for _, _, _, bi in d["launch"]]}
         if d["launch"]:
             rep["first_launch_host_ms_before_backward_end"] = round((t1 - d["launch"][0][0]) * 1e3, 3)
         if e0 is not None and e1 is not None:
             rep["backward_gpu_ms"] = round(e0.elapsed_time(e1), 3)
-            rep["launch_gpu_ms_after_backward_start"] = [round(e0.elapsed_time(ev), 3) for _, ev, _ in d["launch"] if ev is not None]
+            rep["launch_gpu_ms_after_backward_start"] = [round(e0.elapsed_time(ev), 3) for _, ev, _, _ in d["launch"] if ev is not None]
             if d["wait"] is not None:
                 rep["comm_exposed_ms"] = round(d["wait"][0].elapsed_time(d["wait"][1]), 3)
         return rep
@@ -169,7 +188,7 @@ class GradSync:
         b["launched"] = True
         if self._diag is not None and (self.world > 1 or self.force_collective):
             ev = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)) if self.comm_stream is not None else None
-            self._diag["launch"].append((time.perf_counter(), ev, in_finish))
+            self._diag["launch"].append((time.perf_counter(), ev, in_finish, b.get("index", -1)))
         if self.world == 1 and not self.force_collective:
             return
         inv = 1.0 / self.world

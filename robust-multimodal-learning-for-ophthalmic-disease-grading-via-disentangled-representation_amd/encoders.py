@@ -115,6 +115,7 @@ def _bn_bwd(dout, mask, raw, mean, rstd, gamma, want_dres):
 # A block whose layer geometries lack the fused fast paths (edrl_conv2d_fused_ok_f32: tiny / odd maps) keeps the separate
 # passes; the gradient handed from block to block is ("plain", dout) or ("masked", g, part, chunks, planes).
 _FUSE_BN = os.environ.get("EDRL_FUSE_BN", "1") != "0"
+_GRAD_STASH = os.environ.get("EDRL_TRUNK_GRAD_STASH", "1") != "0"   # 0: every pass hands its parameter gradients to the autograd engine
 _STEM_RAW16 = os.environ.get("EDRL_BF16_STEM_RAW16", "1") != "0"    # (bf16 trunk) raw stem conv output stored as bf16, statistics from the conv epilogue
 _STEM_BF16MMA = os.environ.get("EDRL_BF16_STEM_MMA", "1") != "0"   # (bf16 trunk, 1-channel input) stem conv on the bf16 matrix pipe
 _FUSE_STEM = os.environ.get("EDRL_FUSE_STEM", "1") != "0"      # BatchNorm + ReLU of the stem folded into its max-pool (fp32 trunk)
@@ -281,6 +282,19 @@ class _K32:
         return conv_bwd("conv1", draw, x, 2, 3, need_dx=needs_x)
 
 
+# Weight shadows (round 5): inside a train_step the bf16 forward operand and the permuted data-gradient operand of every conv
+# weight of a trunk are made ONCE, by one multi-tensor launch (ResNetTrunk.build_shadows <- train.train_step), instead of one
+# cast + one permute launch per layer and view.  Keyed by the fp32 weight's device pointer; valid from step_begin to step_end
+# (the weights do not change in between); outside a train_step the per-call casts below remain.  EDRL_WEIGHT_SHADOWS=0: off.
+_WEIGHT_SHADOWS = os.environ.get("EDRL_WEIGHT_SHADOWS", "1") != "0"
+_SHADOW_CAST = {}
+
+
+def _wbf16(w):
+    s = _SHADOW_CAST.get(w.data_ptr())
+    return s if s is not None else ops.to_bf16(w)
+
+
 class _KBF16:
     act_dtype = torch.bfloat16
     conv_bn_fwd = staticmethod(lambda *a, **k: _conv_bn_fwd_bf16(*a, **k))
@@ -290,8 +304,8 @@ class _KBF16:
                               ops.conv2d_dgrad_bf16(dy, wt, xshape, s, p, out=out, accumulate=accumulate))
     permute = staticmethod(lambda w: ops.permute_weight_bf16(w))
     fused_ok = staticmethod(lambda *a: ops.conv_fused_ok_bf16(*a))
-    fwd_stats = staticmethod(lambda inp, w, s, p: ops.conv2d_fwd_bf16(inp, ops.to_bf16(w), s, p, stats=True))
-    fwd_bnin_stats = staticmethod(lambda raw, fc, w, s, p: ops.conv2d_fwd_bnin_stats_bf16(raw, fc, ops.to_bf16(w), s, p))
+    fwd_stats = staticmethod(lambda inp, w, s, p: ops.conv2d_fwd_bf16(inp, _wbf16(w), s, p, stats=True))
+    fwd_bnin_stats = staticmethod(lambda raw, fc, w, s, p: ops.conv2d_fwd_bnin_stats_bf16(raw, fc, _wbf16(w), s, p))
     wgrad_bn = staticmethod(lambda *a: ops.conv2d_wgrad_bn_bf16(*a))
     dgrad_bn = staticmethod(lambda *a, **k: ops.conv2d_dgrad_bn_bf16(*a, **k))
     apply_res_name, reduce_name, elt = "edrl_bn_apply_res_bf16", "edrl_bn_bwd_reduce_bf16", 2.0
@@ -420,6 +434,9 @@ class _TrunkFn(torch.autograd.Function):
             cap = {}
             T._capture_seq.append(cap)
         T._wt_cache = {}     # permuted weights are shared by the backward passes that follow this forward
+        ctx.step = T._step   # train_step-scoped state (ResNetTrunk.step_begin): gradient stash of the passes that share the weights
+        if ctx.step is not None:
+            ctx.step["nodes"] += 1
 
         def cb(conv_name, bn_name, inp, stride, pad, relu, residual=None):
             r = K.conv_bn_fwd(inp, p[conv_name + ".weight"], bnd(bn_name, p), stride, pad, relu, residual)
@@ -471,7 +488,8 @@ class _TrunkFn(torch.autograd.Function):
             M = raw.numel() // C
             act = torch.empty_like(raw)
             kb = torch.empty((M, C // 4), device=raw.device, dtype=torch.uint8)
-            L.call("edrl_bn_apply_mx", P(raw), 1, P(fc[0]), P(fc[2]), P(fc[3]), None, P(act), 1, P(kb), M, C, 1)
+            ops.call_timed_bytes("bn_apply", M * C * 4.25, "edrl_bn_apply_mx", P(raw), 1, P(fc[0]), P(fc[2]), P(fc[3]), None, P(act), 1,
+                                 P(kb), M, C, 1)
             return act, kb
 
         p0, saved["stem"] = K.stem_fwd(T, x, p, bnd, cap, cb)
@@ -506,7 +524,8 @@ class _TrunkFn(torch.autograd.Function):
                         M1 = c1.numel() // C1
                         a1 = torch.empty_like(c1)
                         k1 = torch.empty((M1, C1 // 4), device=c1.device, dtype=torch.uint8)
-                        L.call("edrl_bn_apply_mx", P(c1), 1, P(f1[0]), P(f1[2]), P(f1[3]), None, P(a1), 1, P(k1), M1, C1, 1)
+                        ops.call_timed_bytes("bn_apply", M1 * C1 * 4.25, "edrl_bn_apply_mx", P(c1), 1, P(f1[0]), P(f1[2]), P(f1[3]), None,
+                                             P(a1), 1, P(k1), M1, C1, 1)
                         c2, f2 = cf(pre + ".conv2", pre + ".bn2", a1, None, s, 1)
                         rec.update(a1=a1, k1=k1, mid_sep=True)
                         if cap is not None:
@@ -575,6 +594,9 @@ class _TrunkFn(torch.autograd.Function):
 
         def wt_of(name):
             """[Ci,KH,KW,Co] copy of a conv weight for the data gradient, shared by the two views' backward passes."""
+            sh = T._shadow_perm.get(name)
+            if sh is not None:                # made once per train_step for the whole trunk (ResNetTrunk.build_shadows)
+                return sh
             key = (name, torch.cuda.current_stream().cuda_stream)     # (two-stream view overlap: one copy per stream)
             t = wt_cache.get(key)
             if t is None:
@@ -585,6 +607,55 @@ class _TrunkFn(torch.autograd.Function):
         # stream so the MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm-backward kernels of the main stream.
         main = torch.cuda.current_stream()
         side = T.wgrad_stream() if _WGRAD_SIDE_STREAM else None
+
+        # Inside a train_step the passes that share this trunk's weights (the two views) sum their parameter gradients HERE, one
+        # multi-tensor add per residual stage, instead of handing ~160 tensors per pass to the autograd engine (one add kernel
+        # each: 319 launches per step) -- and a stage's gradients are complete, delivered to .grad and reported to the gradient
+        # exchange (ResNetTrunk.grad_sink <- dist.GradSync) as soon as the LAST pass has finished that stage, so encoder buckets
+        # are exchanged during backward instead of after the last trunk node returns.  The sums are the engine's: first + second.
+        st = ctx.step if (ctx.step is not None and ctx.step is T._step) else None
+        stash_mode = None
+        if st is not None and _GRAD_STASH and st["nodes"] > 1 and cap is None:
+            st["done"] += 1
+            stash_mode = "last" if st["done"] >= st["nodes"] else "first"
+
+        def flush(stage):
+            """Stage `stage` ("layer4".."layer1", "stem") of this pass is done."""
+            if stash_mode is None:
+                return
+            if side is not None:
+                main.wait_stream(side)
+            cur = torch.cuda.current_stream()
+            names = [n for n in T.stage_params[stage] if grads.get(n) is not None]
+            stash, ev = st["stash"], st["events"].pop(stage, None)
+            if ev is not None and ev[0] != cur.cuda_stream:
+                cur.wait_event(ev[1])               # the earlier pass ran this stage on another stream (view overlap)
+            dst, src = [], []
+            for n in names:
+                g = grads.pop(n)                    # (popped: the node returns None for it, the engine sees no gradient)
+                d = stash.get(n)
+                if d is None:
+                    pg = T.get(n).grad              # a gradient tensor that is already there: DP bucket view / accumulation
+                    if pg is None:
+                        stash[n] = g                # the first arrival's tensor becomes the accumulator
+                        continue
+                    d = stash[n] = pg
+                dst.append(d); src.append(g)
+            if dst:
+                torch._foreach_add_(dst, src)
+            if stash_mode != "last":
+                st["events"][stage] = (cur.cuda_stream, cur.record_event())
+                return
+            ready = []
+            for n in names:
+                prm, d = T.get(n), stash.pop(n)
+                if ev is not None and ev[0] != cur.cuda_stream:
+                    d.record_stream(cur)
+                if prm.grad is not d:
+                    prm.grad = d
+                ready.append(prm)
+            if T.grad_sink is not None and ready:
+                T.grad_sink(ready)
 
         def conv_bwd(name, dy, inp, stride, pad, need_dx=True, dx_out=None, accumulate=False):
             w = p[name + ".weight"]
@@ -714,7 +785,8 @@ class _TrunkFn(torch.autograd.Function):
                     def draw(g_, raw_, bc_):
                         Cc = raw_.shape[-1]
                         d_ = torch.empty_like(raw_)
-                        L.call("edrl_bn_draw_bf16", P(g_), P(raw_), P(bc_), P(d_), raw_.numel() // Cc, Cc)
+                        ops.call_timed_bytes("bn_draw", raw_.numel() * 6.0, "edrl_bn_draw_bf16", P(g_), P(raw_), P(bc_), P(d_),
+                                             raw_.numel() // Cc, Cc)
                         return d_
 
                     def wg(name, d_, inp, st_, pd_):
@@ -752,6 +824,8 @@ class _TrunkFn(torch.autograd.Function):
                     else:
                         grad_in = ("plain", K.conv_dgrad(d1, wt_of(pre + ".conv1"), tuple(xin.shape), 1, 0, out=dx, accumulate=True))
                     del rec, saved[pre]
+                    if bi == 0 or T.blocks[bi - 1]["name"].split(".")[0] != pre.split(".")[0]:
+                        flush(pre.split(".")[0])
                     continue
                 if bott:
                     c2, f2 = rec["c2"], rec["f2"]
@@ -768,7 +842,7 @@ class _TrunkFn(torch.autograd.Function):
                     if rec.get("mid_sep"):
                         C2c = c2.shape[-1]
                         d2 = torch.empty_like(c2)
-                        L.call("edrl_bn_draw_bf16", P(g2), P(c2), P(b2), P(d2), c2.numel() // C2c, C2c)
+                        ops.call_timed_bytes("bn_draw", c2.numel() * 6.0, "edrl_bn_draw_bf16", P(g2), P(c2), P(b2), P(d2), c2.numel() // C2c, C2c)
                         w2 = p[pre + ".conv2.weight"]
                         grads[pre + ".conv2.weight"] = K.conv_wgrad(d2, rec["a1"], tuple(w2.shape), s, 1)
                         # plain operand (d2 is materialised), epilogue as in the fused chain: masked with bn1's sign bytes,
@@ -810,6 +884,8 @@ class _TrunkFn(torch.autograd.Function):
                            ep_keep=keep_lo)
                 grad_in = ("plain", r) if ep_lo is None else ("masked", r[0], r[1], r[2], 2)
                 del rec, saved[pre]
+                if bi == 0 or T.blocks[bi - 1]["name"].split(".")[0] != pre.split(".")[0]:
+                    flush(pre.split(".")[0])
                 continue
             # ---- separate-pass block
             if grad_in[0] == "masked":      # (not produced: a fused block masks only for a fused block below)
@@ -848,7 +924,10 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 grad_in = ("plain", dx)
             del rec, saved[pre]
+            if bi == 0 or T.blocks[bi - 1]["name"].split(".")[0] != pre.split(".")[0]:
+                flush(pre.split(".")[0])
         dx = K.stem_bwd(T, saved.pop("stem"), p, grad_in[1], grads, cap, bn_bwd, conv_bwd, ctx.needs_x)
+        flush("stem")
         if side is not None:
             main.wait_stream(side)
         return (None, dx) + tuple(grads.get(n) for n in T.param_names)
@@ -866,7 +945,7 @@ def _mask_to_bool(mask, shape):
 def _conv_bn_fwd_bf16(inp, w, bn, stride, pad, relu, residual=None):
     """bf16 conv (fp32 accumulate, BN statistics from the accumulators) -> BN -> (+residual) -> (ReLU), all tensors bf16.
     -> (raw bf16, out bf16, mean, rstd, mask)."""
-    raw, part, chunks = ops.conv2d_fwd_bf16(inp, ops.to_bf16(w), stride, pad, stats=True)
+    raw, part, chunks = ops.conv2d_fwd_bf16(inp, _wbf16(w), stride, pad, stats=True)
     C = raw.shape[-1]
     M = raw.numel() // C
     dev = raw.device
@@ -936,6 +1015,14 @@ class ResNetTrunk(nn.Module):
         self._capture = None
         self._capture_seq = None
         self._wt_cache = {}
+        self._step = None            # per-train_step state (step_begin / step_end)
+        self._shadow_perm = {}       # conv name -> permuted data-gradient operand, valid inside a train_step (build_shadows)
+        self._shadow_state = None
+        self.grad_sink = None        # callable(list of parameters whose .grad is complete): dist.GradSync.params_ready
+        self.stage_params = {}
+        for n in self.param_names:
+            st = n.split(".")[0]
+            self.stage_params.setdefault(st if st.startswith("layer") else "stem", []).append(n)
         self.kernels = _KBF16 if dtype == "bf16" else _K32
         self._register_state_dict_hook(self._save_hook)
         self._register_load_state_dict_pre_hook(self._load_pre_hook)
@@ -1007,6 +1094,59 @@ class ResNetTrunk(nn.Module):
         # the concurrent pass did not touch num_batches_tracked (bump_batches_tracked): its increment is applied here, in
         # order on the joining stream, so the counter advances by exactly 2 per step whatever the streams' interleaving
         torch._foreach_add_([self.get(n + ".num_batches_tracked") for n in self._bn_names], 1)
+
+    # ---- one optimisation step (train.train_step brackets it): weight shadows + the gradient stash of _TrunkFn.backward
+    def step_begin(self):
+        self._step = {"nodes": 0, "done": 0, "stash": {}, "events": {}}
+        if _WEIGHT_SHADOWS:
+            self.build_shadows()
+
+    def step_end(self):
+        st, self._step = self._step, None
+        self.drop_shadows()
+        if st is not None and st["stash"]:
+            raise RuntimeError(f"ResNetTrunk: {len(st['stash'])} parameter gradients of an unfinished backward were left in the "
+                               "step's stash (a forward pass of this step never ran its backward)")
+
+    def build_shadows(self):
+        """bf16 forward operands + permuted data-gradient operands of every conv weight but the stem's, one launch
+        (edrl_weight_shadows_multi).  Buffers and the device table are allocated once and reused while the parameters stay put."""
+        import struct
+        names = [n[:-7] for n in self.param_names if n.endswith(".weight") and n != "conv1.weight" and self.get(n).dim() == 4]
+        ws = [self.get(n + ".weight") for n in names]
+        if not ws or not ws[0].is_cuda:
+            return
+        key = tuple(w.data_ptr() for w in ws)
+        sh = self._shadow_state
+        if sh is None or sh["key"] != key:
+            bf16 = self.compute_dtype == "bf16"
+            dev = ws[0].device
+            ce = L.lib().fn["edrl_adam_chunk_elems"]()
+            recs, chunks, cast, perm = [], [], {}, {}
+            for ti, (n, w) in enumerate(zip(names, ws)):
+                Co, KH, KW, Ci = w.shape
+                c = torch.empty(w.shape, device=dev, dtype=torch.bfloat16) if bf16 else None
+                pm = torch.empty((Ci, KH, KW, Co), device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+                recs.append(struct.pack("QQQiiiiq", w.data_ptr(), c.data_ptr() if c is not None else 0, pm.data_ptr(), Co, KH * KW,
+                                        Ci, 1 if bf16 else 0, w.numel()))
+                chunks.extend((ti, k) for k in range((w.numel() + ce - 1) // ce))
+                if c is not None:
+                    cast[w.data_ptr()] = c
+                perm[n] = pm
+            sh = self._shadow_state = {
+                "key": key, "cast": cast, "perm": perm, "n": len(names), "n_chunks": len(chunks),
+                "table": torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev),
+                "chunks": torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)}
+        L.call("edrl_weight_shadows_multi", sh["table"].data_ptr(), sh["n"], sh["chunks"].data_ptr(), sh["n_chunks"])
+        _SHADOW_CAST.update(sh["cast"])
+        self._shadow_perm = sh["perm"]
+
+    def drop_shadows(self):
+        sh = self._shadow_state
+        if sh is not None:
+            for k in sh["cast"]:
+                _SHADOW_CAST.pop(k, None)
+        self._shadow_perm = {}
 
     def wgrad_stream(self):
         s = getattr(self, "_wgrad_stream", None)

@@ -84,7 +84,7 @@ class Conv3dFn(torch.autograd.Function):
         dw = dx = None
         if vol_w:
             dw = torch.empty(tuple(w.shape), device=dy.device, dtype=torch.float32)
-            nb = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", N * Do, Ho, Wo, Co, CK, KH, KW)
+            nb = L.query("edrl_conv3d_wgrad_workspace_bytes", N, Do, Ho, Wo, Co, C, KD, KH, KW)
             ws = torch.empty(nb // 4, device=dy.device, dtype=torch.float32)
             ops._launch_timed("conv_wgrad", 2.0 * dy4.numel() * KH * KW * CK, "edrl_conv3d_ndhwc_wgrad_f32", P(dy4), P(xs), P(dw), P(ws),
                               nb, N, D, H, W, C, Do, Ho, Wo, Co, KD, KH, KW, sd, s, pd, p, 0,

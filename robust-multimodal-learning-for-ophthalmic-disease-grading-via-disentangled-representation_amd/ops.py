@@ -100,6 +100,7 @@ def _launch_timed(kind, flops, name, *args, kernels=1, nbytes=0.0):
     so that the timer's launch count is the one rocprofv3 sees.  `nbytes`: algorithmic HBM bytes of the call (every operand
     tensor read once, every result written once; weights included)."""
     if _timer is None:
+        L.trace_note(kind=kind, flops=flops, nbytes=nbytes)      # (no-op unless the call tracer is on: _lib.trace_begin)
         L.call(name, *args)
         return
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -114,6 +115,7 @@ def _launch_timed(kind, flops, name, *args, kernels=1, nbytes=0.0):
 def call_timed_bytes(kind, nbytes, name, *args, kernels=1):
     """An HBM-bound launcher bracketed like _launch_timed; `nbytes` = its algorithmic bytes (tensor reads + writes)."""
     if _timer is None:
+        L.trace_note(kind=kind, flops=0.0, nbytes=float(nbytes))
         L.call(name, *args)
         return
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -1102,8 +1104,11 @@ def conv2d_fwd_bf16(x, w, stride=1, pad=0, stats=False):
     if stats:
         chunks = L.query("edrl_conv_stats_chunks", N, Ho, Wo)
         part = torch.empty((chunks, 3, Co), device=x.device, dtype=torch.float32)
+    # algorithmic bytes: a strided 1x1 layer needs only the pixels it samples
+    x_read = x.numel() / (stride * stride) if (KH == 1 and KW == 1) else x.numel()
     _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_fwd_bf16", P(x), P(w), P(out),
-                  P(part), part.numel() * 4 if stats else 0, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad)
+                  P(part), part.numel() * 4 if stats else 0, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad,
+                  nbytes=2.0 * (x_read + w.numel() + out.numel()))
     return (out, part, chunks) if stats else out
 
 
@@ -1115,7 +1120,8 @@ def conv2d_dgrad_bf16(dy, wt, x_shape, stride=1, pad=0, out=None, accumulate=Fal
         out = torch.empty((N, Hi, Wi, Ci), device=dy.device, dtype=torch.bfloat16)
     _launch_timed("conv_gather_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bf16", P(dy), P(wt),
                   P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0,
-                  kernels=_dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate))
+                  kernels=_dgrad_kernels(Hi, Wi, KH, KW, stride, pad, accumulate),
+                  nbytes=2.0 * (dy.numel() + wt.numel() + out.numel() * (2 if accumulate else 1)))
     return out
 
 
@@ -1129,8 +1135,10 @@ def conv2d_wgrad_bf16(dy, x, w_shape, stride=1, pad=0, out=None, accumulate=Fals
         accumulate = False
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_bf16_workspace_bytes", N, Ho, Wo, Co, Ci, KH, KW)
     ws = torch.empty(nbytes // 4, device=dy.device, dtype=torch.float32)
+    x_read = x.numel() / (stride * stride) if (KH == 1 and KW == 1) else x.numel()
     _launch_timed("conv_wgrad_bf16", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_bf16", P(dy), P(x),
-                  P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 1 if accumulate else 0)
+                  P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 1 if accumulate else 0,
+                  nbytes=2.0 * (dy.numel() + x_read) + 4.0 * out.numel())
     return out
 
 

@@ -39,8 +39,10 @@ def device_twin_views(fundus_low, oct_low, sigma=0.5, drop_oct_high=False):
     return [fundus_low, oct_low], [f_high, o_high]
 
 
-# EDRL_VIEW_STREAM=1: overlap the two views' encoder passes on two HIP streams (see train_step).
-_VIEW_STREAM = os.environ.get("EDRL_VIEW_STREAM", "0") == "1"
+# The two views' encoder passes run on two HIP streams (see train_step): the product default since round 5 -- identical losses,
+# gradients and running statistics (tests/test_gpu_head.py::test_view_overlap_streams_same_results), +3 % (C1) / +7 % (C2).
+# EDRL_VIEW_STREAM=0 / set_view_overlap(False): one view after the other on one stream (what per-kernel timing needs).
+_VIEW_STREAM = os.environ.get("EDRL_VIEW_STREAM", "1") != "0"
 _view_stream = None
 
 
@@ -50,6 +52,10 @@ def set_view_overlap(on):
     _VIEW_STREAM = bool(on)
     if on:   # the shared parameters' AccumulateGrad nodes see gradients from two streams: intentional
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
+def view_overlap():
+    return _VIEW_STREAM
 
 
 if _VIEW_STREAM:
@@ -117,6 +123,17 @@ def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None
     optimizer.zero_grad()
     if hasattr(grad_sync, "zero_grad"):
         grad_sync.zero_grad()          # re-attaches the bucket views as .grad (zeroed) after the set_to_none above
+    trunks = model.trunks() if (hasattr(model, "trunks") and model.training and target.is_cuda) else ()
+    for t in trunks:                   # weight shadows for both views; the views' parameter gradients are summed per stage
+        t.step_begin()
+    try:
+        return _train_step_body(model, optimizer, data1, data2, target, epoch, noise1, noise2, grad_sync)
+    finally:
+        for t in trunks:
+            t.step_end()
+
+
+def _train_step_body(model, optimizer, data1, data2, target, epoch, noise1, noise2, grad_sync):
     if _VIEW_STREAM and target.is_cuda and model.training:
         # The two views' encoder passes are independent (they meet in MK_MMD): the second one runs on a side stream so
         # that its HBM-bound BatchNorm kernels overlap the first one's MFMA-bound convolutions and vice versa; autograd

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_VALU_MFMA_COEXEC_CYCLES"; do
   tag=$(echo $c | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmc_c1_$tag
-  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_c1_$tag -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-overlap-leg --no-recompute-leg --no-anchor-leg --no-bf16-legs > $R/gpurun_out/pmc_c1_$tag.log 2>&1; rc=$?; echo "pmc $tag exit=$rc" >> $R/gpurun_out/pmc_c1_$tag.log
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_c1_$tag -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs > $R/gpurun_out/pmc_c1_$tag.log 2>&1; rc=$?; echo "pmc $tag exit=$rc" >> $R/gpurun_out/pmc_c1_$tag.log
   tail -1 $R/gpurun_out/pmc_c1_$tag.log
   [ $rc -eq 0 ] || exit $rc
 done

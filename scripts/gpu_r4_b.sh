@@ -7,7 +7,7 @@ rc=$?; echo "pytest exit=$rc" >> gpurun_out/r4b_pytest.log; tail -5 gpurun_out/r
 grep -E "v3 dgrad epilogue|worst trunk|relative Frobenius" gpurun_out/r4b_pytest.log | tail -30
 [ $rc -eq 0 ] || exit $rc
 for v in 0 1; do
-  EDRL_BF16_WIDE_SEP=$v timeout -k 10 300 python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-recompute-leg --no-overlap-leg > gpurun_out/r4b_c2_wide$v.json 2>/dev/null
+  EDRL_BF16_WIDE_SEP=$v timeout -k 10 300 python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-recompute-leg --in-order > gpurun_out/r4b_c2_wide$v.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/r4b_c2_wide$v.json"))
@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for CFG in C2 C1; do
   rm -rf $R/gpurun_out/trace_$CFG
-  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_$CFG -- python3 $R/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-overlap-leg --no-recompute-leg --no-anchor-leg --no-bf16-legs > /dev/null 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_$CFG -- python3 $R/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs > /dev/null 2>&1
   python3 $R/scripts/trace_by_grid.py $R/gpurun_out/trace_$CFG 2 90 > $R/gpurun_out/r4b_${CFG}_by_grid.txt
   find $R/gpurun_out/trace_$CFG -name "*.csv" -delete
   head -3 $R/gpurun_out/r4b_${CFG}_by_grid.txt

@@ -11,7 +11,7 @@ d=json.load(open("gpurun_out/r4d_c1.json"))
 print("C1 value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], "overlap", d.get("view_overlap",{}).get("value"), {k:round(x["ms_total"]/8,1) for k,x in d["kernels"].items()})
 PY
 for v in 0 1; do
-  EDRL_BF16_STEM_MMA=$v timeout -k 10 300 python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-recompute-leg --no-overlap-leg > gpurun_out/r4d_c2_stem$v.json 2>/dev/null
+  EDRL_BF16_STEM_MMA=$v timeout -k 10 300 python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-recompute-leg --in-order > gpurun_out/r4d_c2_stem$v.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/r4d_c2_stem$v.json"))

@@ -5,7 +5,7 @@ timeout -k 10 600 python -m pytest tests/test_gpu_bf16.py -m gpu -q --timeout 60
 rc=$?; echo "pytest exit=$rc" >> gpurun_out/r4f_pytest.log; tail -3 gpurun_out/r4f_pytest.log
 [ $rc -eq 0 ] || exit $rc
 for v in "EDRL_BF16_K64_BWD=1"; do
-  env $v timeout -k 10 300 python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-recompute-leg --no-overlap-leg > gpurun_out/r4f_c2.json 2>/dev/null
+  env $v timeout -k 10 300 python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-recompute-leg --in-order > gpurun_out/r4f_c2.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/r4f_c2.json"))

@@ -14,7 +14,7 @@ d=json.load(open("gpurun_out/r4h_c2.json"))
 print("persist=$v value", d["value"], "ms", d["ms_per_step"], "overlap", d.get("view_overlap",{}).get("value"), {k:round(x["ms_total"]/5,1) for k,x in d["kernels"].items()})
 PY
 done
-timeout -k 10 300 python bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline --no-recompute-leg --no-overlap-leg > gpurun_out/r4h_c4.json 2>/dev/null
+timeout -k 10 300 python bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline --no-recompute-leg --in-order > gpurun_out/r4h_c4.json 2>/dev/null
 python - <<PY
 import json
 d=json.load(open("gpurun_out/r4h_c4.json"))

@@ -2,7 +2,7 @@
 set -o pipefail
 mkdir -p gpurun_out
 for v in 0 512 1100 0 512; do
-  EDRL_V3_EPI_KMIN=$v timeout -k 10 300 python bench.py --config C2 --steps 6 --warmup 2 --no-cpu-baseline --no-recompute-leg --no-overlap-leg > gpurun_out/r4p_c2.json 2>/dev/null
+  EDRL_V3_EPI_KMIN=$v timeout -k 10 300 python bench.py --config C2 --steps 6 --warmup 2 --no-cpu-baseline --no-recompute-leg --in-order > gpurun_out/r4p_c2.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/r4p_c2.json"))

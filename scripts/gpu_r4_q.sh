@@ -2,7 +2,7 @@
 # round-4 record runs: 50-step lines (SURVEY 8d protocol) for C1 and C2, C4 line, per-layer weight-gradient table
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-overlap-leg --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4q_c1_50.json 2>/dev/null; echo "c1 rc=$?"
+timeout -k 10 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4q_c1_50.json 2>/dev/null; echo "c1 rc=$?"
 timeout -k 10 300 python bench.py --config C2 --steps 50 --warmup 5 --no-cpu-baseline --no-recompute-leg > gpurun_out/r4q_c2_50.json 2>/dev/null; echo "c2 rc=$?"
 timeout -k 10 300 python bench.py --config C4 --steps 6 --warmup 2 --no-cpu-baseline --no-recompute-leg > gpurun_out/r4q_c4.json 2>/dev/null; echo "c4 rc=$?"
 python - <<PY

@@ -3,9 +3,9 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-overlap-leg --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4w_c1_50.json 2>/dev/null; echo "c1 rc=$?"
-timeout -k 10 300 python bench.py --config C1-3D --steps 6 --warmup 2 --no-cpu-baseline --no-overlap-leg --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4w_c1_3d.json 2>/dev/null; echo "c1-3d rc=$?"
-timeout -k 10 300 python bench.py --config C0 --steps 20 --warmup 3 --no-cpu-baseline --no-overlap-leg --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4w_c0.json 2>/dev/null; echo "c0 rc=$?"
+timeout -k 10 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4w_c1_50.json 2>/dev/null; echo "c1 rc=$?"
+timeout -k 10 300 python bench.py --config C1-3D --steps 6 --warmup 2 --no-cpu-baseline --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4w_c1_3d.json 2>/dev/null; echo "c1-3d rc=$?"
+timeout -k 10 300 python bench.py --config C0 --steps 20 --warmup 3 --no-cpu-baseline --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs > gpurun_out/r4w_c0.json 2>/dev/null; echo "c0 rc=$?"
 python - <<PY
 import json
 for f in ("r4w_c1_50","r4w_c1_3d","r4w_c0"):

@@ -44,6 +44,35 @@ def test_argument_errors_are_reported_without_a_gpu(edrl):
     assert fn["edrl_bn_workspace_bytes"](3000, 256) == 3 * 3 * 256 * 4
 
 
+def test_library_allocates_nothing(edrl):
+    """SURVEY.md 8(b) ownership: kernels and launchers never allocate or free -- every workspace is the caller's.  The shared
+    object must not even import an allocating HIP entry point, and the K-split slab of the fp32 gather family is registered by
+    the caller (edrl_gather_ksplit_set_workspace), sized by edrl_gather_ksplit_workspace_bytes."""
+    import glob
+    import os
+    import subprocess
+    L = edrl._lib
+    und = subprocess.run(["nm", "-D", "--undefined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for sym in ("hipMalloc", "hipFree", "hipHostMalloc", "hipMallocAsync", "hipMallocManaged", "hipMemPool"):
+        assert sym not in und, f"libedrl_hip.so imports {sym}"
+    for src in glob.glob(os.path.join(os.path.dirname(L.LIB_PATH), "csrc", "*.h*")):
+        assert "hipMalloc" not in open(src).read(), src
+    fn = L.lib().fn
+    need = fn["edrl_gather_ksplit_workspace_bytes"]()
+    assert need == 256 * 128 * 128 * 4
+    assert fn["edrl_gather_ksplit_set_workspace"](0x1000, need - 1, None) == -28      # too small: refused before any HIP call
+    assert fn["edrl_gather_ksplit_set_workspace"](0x1004, need, None) == -22          # misaligned
+
+
+def test_set_switches_rejects_names_the_library_does_not_read(edrl):
+    L = edrl._lib
+    known = L.library_switches()
+    assert {"EDRL_BF16_V3", "EDRL_GATHER_TAIL_SPLIT", "EDRL_WGRAD_FAST"} <= known
+    for bad in ("EDRL_FUSE_BN", "EDRL_BF16_WIDE_SEP", "EDRL_VIEW_STREAM", "NOT_A_SWITCH"):     # Python-level switches: read at import
+        with pytest.raises(ValueError, match="not a library switch"):
+            L.set_switches(**{bad: 0})
+
+
 def test_cpu_tensors_are_rejected_not_silently_computed(edrl):
     with pytest.raises(RuntimeError, match="HIP-only"):
         edrl.MK_MMD(torch.randn(4, 8), torch.randn(4, 8))

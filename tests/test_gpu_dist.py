@@ -157,3 +157,14 @@ def test_dp1_medfusion_step_rccl():
     assert rep["launch_gpu_ms_after_backward_start"][0] < rep["backward_gpu_ms"], "first bucket leaves before backward ends on the GPU"
     assert sum(rep["launched_in_finish"]) < nb, "hooks must launch buckets during backward, not all of them in finish()"
     assert rep["bytes_exchanged"] > 40e6 and "comm_exposed_ms" in rep
+    # Encoder gradients leave DURING backward (round 5): inside train_step the trunks sum the two views' parameter gradients
+    # per residual stage into the bucket views and report each finished stage to GradSync.params_ready, so a bucket made of
+    # encoder parameters only is issued well before backward ends -- before round 5 every encoder gradient became available
+    # when the last trunk node returned (98 % of backward).
+    enc = [(t, bi) for t, f, bi, fin in zip(rep["launch_gpu_ms_after_backward_start"], rep["launch_encoder_fraction"],
+                                            rep["launch_bucket_index"], rep["launched_in_finish"]) if f == 1.0 and not fin]
+    assert enc, f"no pure-encoder bucket was launched from backward: {rep}"
+    first_enc = min(t for t, _ in enc)
+    print(f"[parity] DP1: first pure-encoder bucket issued at {first_enc:.2f} ms of a {rep['backward_gpu_ms']:.2f} ms backward "
+          f"({len(enc)} encoder buckets issued from backward)")
+    assert first_enc < 0.75 * rep["backward_gpu_ms"], (first_enc, rep["backward_gpu_ms"])

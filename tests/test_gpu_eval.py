@@ -134,11 +134,28 @@ def test_js_divergence_and_twin_view(edrl, dev):
 
 
 def test_salt_pepper_bit_exact_and_prefetcher(edrl, dev):
-    """§8(f) row 3.  (1) salt-and-pepper scatter vs a numpy restatement of add_salt_peper (data_harvard.py:35-48:
-    HWC image, salt then pepper, all channels) and add_salt_peper_3D (:24-33, per OCT slice) on the same coordinate
-    draws: BIT-exact.  (2) DevicePrefetcher: pinned-buffer / side-stream upload one batch ahead yields exactly the
+    """§8(f) row 3.  (0) salt-and-pepper scatter vs the REFERENCE's outputs (fixture), (1) vs a numpy restatement of
+    add_salt_peper (data_harvard.py:35-48: HWC image, salt then pepper, all channels) and add_salt_peper_3D (:24-33, per OCT
+    slice) on a batch of fresh coordinate draws: BIT-exact.  (2) DevicePrefetcher: pinned-buffer / side-stream upload one batch ahead yields exactly the
     loader's batches (low views bit-identical), twin views within [0,1], OCT-drop gives zeros, and feeds train()."""
+    import os
     import numpy as np
+    # (0) against the reference's own outputs (tests/golden/salt_pepper.npz: add_salt_peper on HWC images, add_salt_peper_3D per
+    # OCT slice, with the draws they consumed): bit-exact, and the point count per polarity equals the reference's
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "salt_pepper.npz"))
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32))
+    for tag in ("hwc_a", "hwc_b", "hwc_c"):
+        x, y, amount = fx[f"{tag}_x"], fx[f"{tag}_y"], float(fx[f"{tag}_amount"])
+        xin = torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))[None]).to(dev)            # HWC -> [1,C,H,W]
+        coords = [i32(fx[f"{tag}_{k}"][None]) for k in ("salt_r", "salt_c", "pep_r", "pep_c")]
+        assert coords[0].shape[1] == int(-(-amount * x.shape[0] * x.shape[1] * 0.5 // 1))          # ops.salt_pepper_'s own count
+        got = edrl.ops.salt_pepper_(xin, amount, coords=coords)
+        assert np.array_equal(got[0].cpu().numpy().transpose(1, 2, 0), y), tag
+    for tag in ("oct_a", "oct_b"):
+        x, y, amount = fx[f"{tag}_x"], fx[f"{tag}_y"], float(fx[f"{tag}_amount"])
+        xin = torch.from_numpy(x[:, None].copy()).to(dev)                                         # [S,H,W] -> [S,1,H,W]
+        got = edrl.ops.salt_pepper_(xin, amount, coords=[i32(fx[f"{tag}_{k}"]) for k in ("salt_r", "salt_c", "pep_r", "pep_c")])
+        assert np.array_equal(got[:, 0].cpu().numpy(), y), tag
     rng = np.random.RandomState(0)
     N, C, H, W, amount = 3, 3, 37, 41, 0.05
     x = rng.rand(N, C, H, W).astype(np.float32)

@@ -162,3 +162,24 @@ def test_c0_plumbing_epoch_on_cpu(edrl):
         assert all(g is not None for g in out["grads"].values())
     assert all(l == l and l < 1e3 for l in losses)
     assert int(orc.state["DILR.bn1.num_batches_tracked"]) == 8     # 4 updates per step (quirk Q5)
+
+
+def test_salt_pepper_oracle_vs_reference_fixture():
+    """the numpy restatement (oracle/data_oracle.py) reproduces the outputs of the reference's own
+    add_salt_peper / add_salt_peper_3D (code/data_harvard.py:24-48; tests/golden/salt_pepper.npz, cut by oracle/gen_golden.py
+    from the reference's syntax tree with the coordinate draws recorded) BIT for bit, on the recorded draws."""
+    import os
+    import numpy as np
+    from oracle import data_oracle as D
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "salt_pepper.npz"))
+    for tag in ("hwc_a", "hwc_b", "hwc_c"):
+        x, y = fx[f"{tag}_x"], fx[f"{tag}_y"]
+        got = D.salt_pepper_hwc(x, fx[f"{tag}_salt_r"], fx[f"{tag}_salt_c"], fx[f"{tag}_pep_r"], fx[f"{tag}_pep_c"])
+        assert np.array_equal(got, y), tag
+        assert len(fx[f"{tag}_salt_r"]) == len(fx[f"{tag}_pep_r"]) == D.salt_pepper_count(float(fx[f"{tag}_amount"]), x.shape[0], x.shape[1])
+        assert int(fx[f"{tag}_salt_r"].max()) < x.shape[0] - 1 and int(fx[f"{tag}_salt_c"].max()) < x.shape[1] - 1   # randint(0, size - 1)
+    for tag in ("oct_a", "oct_b"):
+        x, y = fx[f"{tag}_x"], fx[f"{tag}_y"]
+        for i in range(x.shape[0]):
+            got = D.salt_pepper_hwc(x[i], fx[f"{tag}_salt_r"][i], fx[f"{tag}_salt_c"][i], fx[f"{tag}_pep_r"][i], fx[f"{tag}_pep_c"][i])
+            assert np.array_equal(got, y[i]), (tag, i)
