@@ -88,13 +88,19 @@ class GradSync:
             b["encoder_fraction"] = enc / max(b["flat"].numel(), 1)
         if self.params and self.params[0].is_cuda:
             self.comm_stream = torch.cuda.Stream()
-        for p in self.params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         # The encoder trunks sum the two views' parameter gradients themselves, stage by stage, straight into the bucket views
-        # (encoders._TrunkFn.backward: no autograd hook fires for them inside a train_step) and report every finished residual
-        # stage here -- so encoder buckets go out during backward, not after the last trunk node has returned.
+        # (encoders._TrunkFn.backward inside a train_step) and report every finished residual stage to params_ready -- so encoder
+        # buckets go out during backward, not after the last trunk node has returned.  The trunk nodes then hand the engine no
+        # gradient for those parameters; their post-accumulate hooks still fire (with nothing accumulated) once the last node
+        # has returned and are ignored while the trunk manages its gradients itself (ResNetTrunk.stash_active).
+        self._trunk_of = {}
         for t in (model.trunks() if hasattr(model, "trunks") else ()):
             t.grad_sink = self.params_ready
+            for p in t.parameters():
+                self._trunk_of[p] = t
+        self.hook_calls_ignored = 0
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
 
     # ---- step protocol: zero_grad() -> forward/backward (hooks launch full buckets) -> finish() -> optimizer.step()
     def zero_grad(self):
@@ -118,6 +124,13 @@ class GradSync:
             yield
         finally:
             self._sync = old
+
+    def _hook(self, p):
+        t = self._trunk_of.get(p)
+        if t is not None and t.stash_active():
+            self.hook_calls_ignored += 1
+            return
+        self._on_grad(p)
 
     def _on_grad(self, p):
         b = self.buckets[self.index[p]]

@@ -1101,6 +1101,11 @@ class ResNetTrunk(nn.Module):
         if _WEIGHT_SHADOWS:
             self.build_shadows()
 
+    def stash_active(self):
+        """True while the passes of the current train_step sum this trunk's parameter gradients themselves (_TrunkFn.backward)."""
+        st = self._step
+        return st is not None and _GRAD_STASH and st["nodes"] > 1 and self._capture is None and self._capture_seq is None
+
     def step_end(self):
         st, self._step = self._step, None
         self.drop_shadows()
