@@ -14,15 +14,14 @@ them on the CPU in the reference's call order (fusion_net.py:105-110, 44-45, 907
 run seeded like the reference consumes the global CPU generator identically; rng="device" draws
 on the GPU (no host->device copy).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib as L
 from . import ops
 from .encoders import FundusEncoder, OCTSliceEncoder
-
-
-import os
 
 # EDRL_FUNDUS_STREAM=1: run the fundus encoder on a side stream concurrently with the OCT encoder (opt-in).
 _FUNDUS_SIDE_STREAM = os.environ.get("EDRL_FUNDUS_STREAM", "0") == "1"
@@ -188,8 +187,7 @@ class AttentionModel(nn.Module):
     def forward(self, x, y, z):
         assert y is z, "EDRL only uses key is value (fusion_net.py:733-734,742-743)"
         E, a = self.embed_size, self.attn
-        q = ops.linear(x, a.in_proj_weight[:E], a.in_proj_bias[:E])
-        kv = ops.linear(y, a.in_proj_weight[E:], a.in_proj_bias[E:])               # keys | values, one GEMM
+        q, kv = ops.in_proj(x, y, a.in_proj_weight, a.in_proj_bias, E)             # queries; keys | values in one GEMM
         ctx = ops.mha_core(q, kv, self.num_heads)
         attn_output = ops.linear(ctx, a.out_proj.weight, a.out_proj.bias)
         attn_output = ops.add(x, attn_output)

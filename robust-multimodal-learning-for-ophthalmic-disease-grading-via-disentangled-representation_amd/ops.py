@@ -402,22 +402,48 @@ def linear_fwd(x2, w, bias=None, mul=None, relu=False):
     return out
 
 
+# Permuted [in, out] copies of the head's Linear weights for the input gradients: inside a train_step (train.train_step brackets
+# it with step_cache_begin / _end) every weight is permuted once and the copy serves both views' backward passes; outside, per call.
+_perm_cache = None
+
+
+def step_cache_begin():
+    global _perm_cache
+    _perm_cache = {}
+
+
+def step_cache_end():
+    global _perm_cache
+    _perm_cache = None
+
+
+def _permuted(w):
+    if _perm_cache is None:
+        return permute_weight(w)
+    key = (w.data_ptr(), tuple(w.shape), torch.cuda.current_stream().cuda_stream)
+    t = _perm_cache.get(key)
+    if t is None:
+        t = _perm_cache[key] = permute_weight(w)
+    return t
+
+
 def linear_dgrad(dy2, w):
     """dy2 [rows, out], w [out, in] -> dx [rows, in]."""
     rows, cout = dy2.shape
     cin = w.shape[1]
-    wt = permute_weight(w)  # [in, out]
+    wt = _permuted(w)  # [in, out]
     out = torch.empty((rows, cin), device=dy2.device, dtype=torch.float32)
     _launch_timed("linear_gather", 2.0 * rows * cin * cout, "edrl_conv2d_nhwc_dgrad_f32", P(dy2), P(wt), P(out), rows,
                   1, 1, cin, 1, 1, cout, 1, 1, 1, 0, _ld(dy2), cin, 0)
     return out
 
 
-def matmul_tn(a2, b2):
-    """a2 [rows, M], b2 [rows, N] (row strides allowed) -> a2^T @ b2  [M, N] (split-K over rows)."""
+def matmul_tn(a2, b2, out=None):
+    """a2 [rows, M], b2 [rows, N] (row strides allowed) -> a2^T @ b2  [M, N] (split-K over rows); `out`: contiguous [M, N] target."""
     rows, M = a2.shape
     N = b2.shape[1]
-    out = torch.empty((M, N), device=a2.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((M, N), device=a2.device, dtype=torch.float32)
     nbytes = L.query("edrl_conv2d_nhwc_wgrad_workspace_bytes", rows, 1, 1, M, N, 1, 1)
     ws = torch.empty(max(nbytes // 4, 1), device=a2.device, dtype=torch.float32)
     _launch_timed("linear_wgrad", 2.0 * rows * M * N, "edrl_conv2d_nhwc_wgrad_f32", P(a2), P(b2), P(out), P(ws), nbytes,
@@ -425,9 +451,10 @@ def matmul_tn(a2, b2):
     return out
 
 
-def sum_axis1(x3, scale=1.0):
+def sum_axis1(x3, scale=1.0, out=None):
     A, Ln, D = x3.shape
-    out = torch.empty((A, D), device=x3.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((A, D), device=x3.device, dtype=torch.float32)
     L.call("edrl_sum_axis1_f32", P(x3), P(out), A, Ln, D, float(scale))
     return out
 
@@ -439,10 +466,10 @@ def bcast_axis1(x2, Ln, scale=1.0):
     return out
 
 
-def colsum(x2):
-    """[rows, D] -> [D]"""
+def colsum(x2, out=None):
+    """[rows, D] -> [D]; `out`: contiguous [D] target."""
     x2 = x2.contiguous()
-    return sum_axis1(x2.view(1, x2.shape[0], x2.shape[1])).view(-1)
+    return sum_axis1(x2.view(1, x2.shape[0], x2.shape[1]), out=None if out is None else out.view(1, -1)).view(-1)
 
 
 # ------------------------------------------------------------------ autograd functions
@@ -481,6 +508,48 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, w, b=None, relu=False, mask=None):
     return LinearFn.apply(x, w, b, relu, mask)
+
+
+class InProjFn(torch.autograd.Function):
+    """The packed in-projection of nn.MultiheadAttention for key is value (fusion_net.py:569-570, 733-743):
+    q = x @ W[:E]^T + b[:E],  kv = y @ W[E:]^T + b[E:]  with W = in_proj_weight [3E, E].  One node, so that the packed weight and
+    bias get ONE gradient tensor written slice by slice; slicing the parameter in Python instead makes autograd build a
+    zero-filled [3E, E] tensor per slice, copy the slice gradient in and add the two (5 launches and 3 x 12.6 MB of traffic per
+    parameter and call: 80 launches per step for the four attention blocks and two views)."""
+
+    @staticmethod
+    def forward(ctx, x, y, w, b, E):
+        _chk(x, "in_proj.x", contiguous=False); _chk(y, "in_proj.y", contiguous=False); _chk(w, "in_proj.w"); _chk(b, "in_proj.b")
+        x2, y2 = _rows2d(x), _rows2d(y)
+        q = linear_fwd(x2, w[:E], b[:E])
+        kv = linear_fwd(y2, w[E:], b[E:])
+        ctx.save_for_backward(x2, y2, w)
+        ctx.E, ctx.xshape, ctx.yshape = E, x.shape, y.shape
+        return q.view(*x.shape[:-1], E), kv.view(*y.shape[:-1], 2 * E)
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        x2, y2, w = ctx.saved_tensors
+        E = ctx.E
+        gq, gkv = _rows2d(dq.contiguous()), _rows2d(dkv.contiguous())
+        dx = dy = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(gq, w[:E]).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dy = linear_dgrad(gkv, w[E:]).view(ctx.yshape)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w)
+            matmul_tn(gq, x2, out=dw[:E])
+            matmul_tn(gkv, y2, out=dw[E:])
+        if ctx.needs_input_grad[3]:
+            db = torch.empty((3 * E,), device=w.device, dtype=torch.float32)
+            colsum(gq, out=db[:E])
+            colsum(gkv, out=db[E:])
+        return dx, dy, dw, db, None
+
+
+def in_proj(x, y, w, b, E):
+    return InProjFn.apply(x, y, w, b, E)
 
 
 class ReluFn(torch.autograd.Function):

@@ -126,9 +126,11 @@ def train_step(model, optimizer, data, target, epoch=0, noise1=None, noise2=None
     trunks = model.trunks() if (hasattr(model, "trunks") and model.training and target.is_cuda) else ()
     for t in trunks:                   # weight shadows for both views; the views' parameter gradients are summed per stage
         t.step_begin()
+    ops.step_cache_begin()             # (the head's permuted Linear weights: one copy per step instead of one per view)
     try:
         return _train_step_body(model, optimizer, data1, data2, target, epoch, noise1, noise2, grad_sync)
     finally:
+        ops.step_cache_end()
         for t in trunks:
             t.step_end()
 

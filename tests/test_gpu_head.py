@@ -358,7 +358,9 @@ def test_train_step_bf16_resnet50_vs_storage_aware_oracle(edrl, dev):
         loss:            the same with a 2e-2 floor (the loss is a sum of terms whose storage drifts partly cancel in S: measured
                          d(S, U) 1.2e-4 next to d(P, U) 5.5e-3 on MI355X; the logits themselves drift by 0.26 of the largest logit
                          through bf16 storage alone at this depth and batch -- random-init logits are a cancellation of O(1) terms)
-        every gradient:  cos(P, S) >= cos(S, U) - 0.05  (>= 0.9 outright for the head, whose inputs are fp32)
+        gradients:       tensors that bf16 storage leaves well conditioned (cos(S, U) >= 0.9; at this size only the classifier's
+                         four): cos(P, S) >= cos(S, U) - 0.05 and |P| / |S| in [0.8, 1.25]; all others (direction and size are
+                         storage noise there: cos(S, U) itself is 0.04-0.4): median |P| / |S| in [0.8, 1.25], 90 % within [0.5, 2]
     with the measured values printed.  No decision pinning here: bf16 storage moves thousands of ReLU decisions by itself."""
     from oracle import step_oracle as SO
     from util import relerr
@@ -389,7 +391,7 @@ def test_train_step_bf16_resnet50_vs_storage_aware_oracle(edrl, dev):
     assert lPU <= 1.5 * lSU + 2e-2 and lPS <= 2.0 * lSU + 2e-2, (lSU, lPU, lPS)
     named = dict(m.named_parameters())
     cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-300))
-    worst, rows = 1.0, []
+    rows = []
     for n, gS in rS["grads"].items():
         key = n
         if ".trunk." in n:
@@ -400,16 +402,31 @@ def test_train_step_bf16_resnet50_vs_storage_aware_oracle(edrl, dev):
         gU = rU["grads"][n]
         if float(gS.norm()) == 0.0 or float(gU.norm()) == 0.0:
             continue
-        cPS, cSU = cos(g.cpu().double(), gS), cos(gS, gU)
-        rows.append((cPS - cSU, cPS, cSU, n))
-        worst = min(worst, cPS)
-    rows.sort()
-    for dlt, cPS, cSU, n in rows[:6]:
-        print(f"[parity]   {n}: cos(P,S) {cPS:.4f}  cos(S,U) {cSU:.4f}")
-    bad = [f"{n}: cos(P,S) {cPS:.4f} < cos(S,U) {cSU:.4f} - 0.05" for dlt, cPS, cSU, n in rows
-           if cPS < cSU - 0.05 or (".trunk." not in n and "token_proj" not in n and cPS < min(0.9, cSU))]
+        gP = g.cpu().double()
+        rows.append((cos(gS, gU), cos(gP, gS), float(gP.norm() / gS.norm()), n))
+    # Which gradients CAN be compared is decided by the two oracles alone: through 2 x 53 train-mode BatchNorm layers at 40 images
+    # per trunk pass, bf16 storage by itself decorrelates the early layers' gradients (measured: cos(S, U) 0.04-0.36 on the stems
+    # and layer1's BatchNorm parameters) -- no implementation can agree with either oracle there.  Tensors the storage rounding
+    # leaves well conditioned (cos(S, U) >= 0.9) bind the product directionally and in norm; the others bind in norm only.
+    good = [r for r in rows if r[0] >= 0.9]
+    rest = [r for r in rows if r[0] < 0.9]
+    print(f"[parity] R50 bf16 step: {len(rows)} gradient tensors, {len(good)} well conditioned under bf16 storage (cos(S,U) >= 0.9), "
+          f"{len(rest)} not (min cos(S,U) {min(r[0] for r in rows):.3f})")
+    for cSU, cPS, ratio, n in sorted(good, key=lambda r: r[1] - r[0])[:5]:
+        print(f"[parity]   conditioned, worst: {n}: cos(P,S) {cPS:.4f}  cos(S,U) {cSU:.4f}  |P|/|S| {ratio:.3f}")
+    for cSU, cPS, ratio, n in sorted(rest, key=lambda r: abs(r[2] - 1.0), reverse=True)[:5]:
+        print(f"[parity]   unconditioned, worst norm: {n}: cos(P,S) {cPS:.4f}  cos(S,U) {cSU:.4f}  |P|/|S| {ratio:.3f}")
+    assert len(good) >= 3, "the comparison needs tensors that bf16 storage leaves well conditioned"
+    bad = [f"{n}: cos(P,S) {cPS:.4f} < cos(S,U) {cSU:.4f} - 0.05" for cSU, cPS, ratio, n in good if cPS < cSU - 0.05]
+    bad += [f"{n}: |P|/|S| = {ratio:.3f} outside [0.8, 1.25]" for cSU, cPS, ratio, n in good if not 0.8 <= ratio <= 1.25]
     assert not bad, "; ".join(bad[:6])
-    print(f"[parity] R50 bf16 step: {len(rows)} gradient tensors, worst cos(product, storage-aware fp64) {worst:.4f}")
+    # everything else: direction AND size are storage noise tensor by tensor (|P|/|S| up to 2.9 where cos(S, U) is 0.1-0.2), so the
+    # bound is statistical -- nine tensors in ten within a factor of two of the oracle's norm, the median within 25 %
+    ratios = sorted(r[2] for r in rest)
+    inside = sum(1 for x in ratios if 0.5 <= x <= 2.0) / len(ratios)
+    med = ratios[len(ratios) // 2]
+    print(f"[parity] R50 bf16 step: unconditioned tensors: median |P|/|S| {med:.3f}, {100 * inside:.1f} % within [0.5, 2], max {ratios[-1]:.2f}")
+    assert inside >= 0.9 and 0.8 <= med <= 1.25, (inside, med)
 
 
 @pytest.mark.parametrize("dtype,depth,overlap", [("fp32", 18, False), ("fp32", 18, True), ("bf16", 50, False), ("bf16", 50, True)])
