@@ -513,6 +513,17 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
   return 0;
 }
 
+// EDRL_BF16_V3S: which plain-operand layers take the small-tile LDS-DMA core (conv_bf16_v3s.hip) instead of the 256 x 256 core or
+// the register-staged 128-row kernel.  Mode 2: every geometry it can run.  Auto (1): the HBM-leaning members -- K up to
+// EDRL_V3S_KMAX (512) with at least 128 output channels and enough rows to fill the chip twice over; the K-heavy 3x3 layers of
+// stages 3-4 keep the 256 x 256 core (1.1 PFLOP/s there: a 128 x 128 tile reads each LDS fragment for half as many MFMAs).
+static bool gather_bf16_v3s_pick(const GatherGeom& g) {
+  const int mode = edrl_cfg().bf16_v3s;
+  if (mode == 0 || !gather_bf16_v3s_can(g)) return false;
+  if (mode == 2) return true;
+  return g.Ktot <= edrl_cfg().v3s_kmax && g.NC >= 128 && (long)edrl_cdiv(g.M, 128) * (g.NC / 128) >= 1024;
+}
+
 template <int BN, bool DGRAD>
 static int launch_gather_bf16(const __bf16* src, const __bf16* wm, __bf16* dst, const GatherGeom& g, hipStream_t st) {
   const long ohw = (long)g.OHs * g.OWs;
@@ -924,6 +935,7 @@ int edrl_conv2d_nhwc_fwd_bf16(const void* x, const void* w, void* y, float* stat
     g.flags |= GF_STATS;
     g.stat_part = stat_part;
   }
+  if (gather_bf16_v3s_pick(g)) return launch_gather_bf16_v3s(x, w, y, g, false, st);         // HBM-leaning layers: 128x128 LDS-DMA core, 2 per CU
   if (gather_bf16_v3_ok(g, false)) return launch_gather_bf16_v3(x, w, y, g, false, st);      // K-heavy layers: 256x256 LDS-DMA core
   if (Hi == Ho && Wi == Wo && !((uintptr_t)y & 15) && conv1x1_k64_ok(N, Hi, Wi, Ci, Co, KH, KW, stride, pad))
     return launch_conv1x1_k64(x, nullptr, w, y, N, Hi, Wi, Ci, Co, stat_part, st);                    // 64 -> 128..512 1x1: streaming kernel
@@ -965,7 +977,8 @@ int edrl_conv2d_nhwc_dgrad_bf16(const void* dy, const void* wt, void* dx, int N,
       g.Ktot = g.KHs * g.KWs * Co;
       if (g.Ktot == 0 && (flags & GF_ACCUM)) continue;
       g.M = (int)((long)N * g.OHs * g.OWs);
-      const int rc = gather_bf16_v3_ok(g, true) ? launch_gather_bf16_v3(dy, wt, dx, g, true, st)
+      const int rc = gather_bf16_v3s_pick(g) ? launch_gather_bf16_v3s(dy, wt, dx, g, true, st)
+                     : gather_bf16_v3_ok(g, true) ? launch_gather_bf16_v3(dy, wt, dx, g, true, st)
                      : Ci <= 64 ? launch_gather_bf16<64, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st)
                                 : launch_gather_bf16<128, true>((const __bf16*)dy, (const __bf16*)wt, (__bf16*)dx, g, st);
       if (rc) return rc;
@@ -1177,7 +1190,9 @@ int edrl_conv2d_nhwc_dgrad_bn_bf16(const void* g_in, const void* yraw, const flo
       F.ep_chunk0 = chunk0;
       // wide layers with a materialised d_raw: the 256x256 LDS-DMA core with the masking + partial-sum epilogue
       const bool v3e = plain_in && gather_bf16_v3_ok(g, true) && gather_bf16_v3_epi_ok(g, F) && g.Ktot >= edrl_cfg().v3_epi_kmin;
-      const int rc = v3e ? launch_gather_bf16_v3(g_in, wt, dx, g, true, st, &F)
+      const bool v3s = plain_in && ep_raw && gather_bf16_v3_epi_ok(g, F) && gather_bf16_v3s_pick(g);
+      const int rc = v3s ? launch_gather_bf16_v3s(g_in, wt, dx, g, true, st, &F)
+                     : v3e ? launch_gather_bf16_v3(g_in, wt, dx, g, true, st, &F)
                      : plain_in ? dispatch_gather_fused_bf16<true, 0, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)
                      : ep_raw ? dispatch_gather_fused_bf16<true, 2, 1>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st)
                               : dispatch_gather_fused_bf16<true, 2, 0>((const __bf16*)g_in, (const __bf16*)wt, (__bf16*)dx, g, F, st);

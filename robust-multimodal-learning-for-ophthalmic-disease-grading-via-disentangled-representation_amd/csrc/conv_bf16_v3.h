@@ -55,3 +55,11 @@ int launch_gather_bf16_v3p(const void* src, const void* wm, void* dst, const Gat
 int stem_wgrad_s2d_bf16_splits(int N, int Hs, int Ws);
 size_t stem_wgrad_s2d_bf16_workspace_bytes(int N, int Hs, int Ws);
 int launch_stem_wgrad_s2d_bf16(const void* dy, const float* xs, float* slabs, int N, int Hs, int Ws, hipStream_t st);
+
+// Small-tile form of the core (conv_bf16_v3s.hip: 128 x 128 tile, 4 waves, 64 KiB ring, two workgroups per CU): plain forward / data
+// gradient (GF_STATS, GF_ACCUM, strided classes) and the data gradient with the BatchNorm-backward epilogue (fuse->ep_x != NULL).
+// gather_bf16_v3s_can: the geometry can run there (SC % 32, NC % 128, descriptor footprints); which layers SHOULD is decided in
+// conv_bf16.hip (EDRL_BF16_V3S).
+bool gather_bf16_v3s_can(const GatherGeom& g);
+int launch_gather_bf16_v3s(const void* src, const void* wm, void* dst, const GatherGeom& g, bool dgrad, hipStream_t st,
+                           const GatherFuse* fuse = nullptr);

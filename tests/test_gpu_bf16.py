@@ -95,6 +95,7 @@ def test_conv_bf16_v3_core_vs_fp64_and_v2(edrl, dev, case, persist, switches):
     Ho, Wo = y.shape[2], y.shape[3]
     outs = {}
     switches(EDRL_BF16_V3_PERSIST=persist)      # "1": the persistent form (conv_bf16_v3p.hip: register epilogue, next tile prefetched)
+    switches(EDRL_BF16_V3S="0")                 # (the small-tile core has its own test below)
     for mode in ("0", "2"):
         switches(EDRL_BF16_V3=mode)
         yh, part, chunks = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), s, p, stats=True)
@@ -711,6 +712,68 @@ def test_fused_bn_backward_large_mean_bf16(edrl, dev, geom, c64, switches):
     assert err <= 2 ** -7
 
 
+V3S_CASES = V3_CASES + [
+    (3, 128, 14, 14, 128, 3, 1, 1),      # 128-channel layers: what the 256 x 256 core cannot take
+    (2, 128, 13, 11, 384, 3, 2, 1),
+    (5, 32, 9, 7, 128, 1, 1, 0),         # K = 32: one ring unit
+    (2, 512, 28, 28, 128, 1, 1, 0),
+    (1, 128, 5, 5, 128, 3, 1, 1),        # 25 rows: less than one tile, upper wave row entirely past the end
+    (3, 128, 9, 9, 128, 1, 1, 0),        # 243 rows: the second tile's upper wave row is past the end (statistics re-base with nb = 0)
+]
+
+
+@pytest.mark.parametrize("case", V3S_CASES)
+def test_conv_bf16_v3s_core_vs_fp64_and_128row_kernel(edrl, dev, case, switches):
+    """The 128x128 small-tile LDS-DMA core (csrc/conv_bf16_v3s.hip: 4 waves, 64 KiB ring, two workgroups per CU), forced on
+    (EDRL_BF16_V3S=2) wherever its geometry allows: forward with the BatchNorm chunk partials (one 128-row chunk per tile, the two
+    wave rows re-based and combined through LDS), data gradient plain / accumulating / stride-2 parity classes -- against the
+    fp64 convolution of the same bf16 operands at one bf16 ulp, the partials against fp64 sums over the output rows, and
+    against the 128-row kernel (EDRL_BF16_V3S=0, EDRL_BF16_V3=0)."""
+    ops = edrl.ops
+    N, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(35)
+    x = torch.randn(N, H, W, Ci, generator=g).bfloat16()
+    w = (torch.randn(Co, k, k, Ci, generator=g) * 0.1).bfloat16()
+    xd = nchw(x.double()).requires_grad_(True)
+    wd = w.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.conv2d(xd, wd, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.double())
+    outs = {}
+    switches(EDRL_BF16_V3="0", EDRL_BF16_K64="0", EDRL_BF16_C64="0")
+    for mode in ("0", "2"):
+        switches(EDRL_BF16_V3S=mode)
+        yh, part, chunks = ops.conv2d_fwd_bf16(x.to(dev), w.to(dev), s, p, stats=True)
+        dxh = dxa = None
+        if Ci % 128 == 0:
+            wt = ops.permute_weight_bf16(w.float().to(dev))
+            dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+            dxh = ops.conv2d_dgrad_bf16(dyh, wt, (N, H, W, Ci), s, p)
+            dxa = ops.conv2d_dgrad_bf16(dyh, wt, (N, H, W, Ci), s, p, out=dxh.clone(), accumulate=True)
+        torch.cuda.synchronize()
+        outs[mode] = (yh.float().cpu(), part.cpu(), dxh.float().cpu() if dxh is not None else None,
+                      dxa.float().cpu() if dxa is not None else None)
+    yv, pv, dv, dav = outs["2"]
+    check(f"v3s conv_fwd{case}", nchw(yv), y, BF16_TOL)
+    check(f"v3s vs 128-row conv_fwd{case}", yv, outs["0"][0], BF16_TOL)
+    rows = y.detach().permute(0, 2, 3, 1).reshape(-1, Co)
+    M = rows.shape[0]
+    assert pv.shape[0] == (M + 127) // 128
+    for c in range(pv.shape[0]):
+        blk = rows[c * 128:min(M, (c + 1) * 128)]
+        K = pv[c, 2].double()
+        assert float((K - blk[0]).abs().max()) <= BF16_TOL * float(rows.abs().max()), "shift = the chunk's first row (fp32 accumulator)"
+        d = blk - K
+        sc = max(float(d.abs().sum(0).max()), 1e-6)
+        assert float((pv[c, 0].double() - d.sum(0)).abs().max()) <= 1e-3 * sc, f"chunk {c} S1"
+        sc2 = max(float((d * d).sum(0).max()), 1e-6)
+        assert float((pv[c, 1].double() - (d * d).sum(0)).abs().max()) <= 1e-3 * sc2, f"chunk {c} S2"
+    if dv is not None:
+        check(f"v3s conv_dgrad{case}", nchw(dv), xd.grad, BF16_TOL)
+        check(f"v3s conv_dgrad_accum{case}", nchw(dav), 2 * xd.grad, 2 * BF16_TOL)
+        check(f"v3s vs 128-row conv_dgrad{case}", dv, outs["0"][2], BF16_TOL)
+
+
 V3_EPI_CASES = [
     # N, Hi, Wi, Ci (dx channels, multiple of 256), Co, k, s, p, accumulate, sign bytes?
     (3, 14, 14, 256, 256, 3, 1, 1, False, True),
@@ -725,8 +788,9 @@ V3_EPI_CASES = [
 ]
 
 
-@pytest.mark.parametrize("persist", ["2", "3", "0"])      # persistent with LDS-staged rows / persistent register form / one tile per workgroup
-@pytest.mark.parametrize("case", V3_EPI_CASES)
+@pytest.mark.parametrize("persist", ["2", "3", "0", "v3s"])      # persistent with LDS-staged rows / persistent register form / one tile per workgroup / the 128x128 small-tile core
+@pytest.mark.parametrize("case", V3_EPI_CASES + [(3, 14, 14, 128, 128, 3, 1, 1, False, True), (2, 13, 11, 128, 512, 1, 1, 0, True, False),
+                                                 (4, 28, 28, 384, 128, 3, 2, 1, False, True)])
 def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, persist, switches):
     """The BatchNorm-backward epilogue of the 256x256 LDS-DMA data-gradient core (conv_bf16_v3.hip EPI 1: accumulate, mask with
     the sign bytes / the recomputed ReLU decision of the BatchNorm below, (sum g, sum g*(x - mean)) per 128-row chunk), forced on
@@ -758,8 +822,15 @@ def test_conv_dgrad_v3_epilogue_vs_fp64_and_128row_kernel(edrl, dev, case, persi
     wt = ops.permute_weight_bf16(w.float().to(dev))
     outs = {}
     switches(EDRL_BF16_V3_PERSIST=persist)      # "2" / "3": conv_bf16_v3p.hip (EPI 2 / EPI 1), "0": conv_bf16_v3.hip
+    if persist == "v3s":                        # the small-tile core's epilogue (conv_bf16_v3s.hip EPI 1) against the 128-row kernel's
+        switches(EDRL_BF16_V3_PERSIST="1", EDRL_BF16_V3="0")
+    else:
+        switches(EDRL_BF16_V3S="0")
     for mode in ("0", "2"):
-        switches(EDRL_BF16_V3=mode)
+        if persist == "v3s":
+            switches(EDRL_BF16_V3S=mode)
+        else:
+            switches(EDRL_BF16_V3=mode)
         dst = old.clone().to(dev) if accum else None
         gm, part, chunks = ops.conv2d_dgrad_bn_bf16(dy.to(dev), None, None, wt, (N, H, W, Ci), s, p, out=dst, accumulate=accum,
                                                     ep=(xraw.to(dev), mask.to(dev) if use_mask else None, fc.to(dev), True))

@@ -132,8 +132,8 @@ BF16_GEOMS = [  # N, H, W, Ci, Co, k, stride, pad : channel counts the 256x256 L
 ]
 
 
-@pytest.mark.parametrize("mode", ["0", "2"])
-@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", BF16_GEOMS)
+@pytest.mark.parametrize("mode", ["0", "2", "v3s"])
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", BF16_GEOMS + [(2, 7, 5, 128, 128, 3, 1, 1), (3, 5, 3, 128, 384, 1, 2, 0), (5, 9, 9, 128, 128, 1, 1, 0)])
 def test_bf16_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, Co, k, s, p, mode, switches):
     """The same guard-band check for the bf16 launchers: forward (+ BatchNorm partials), data gradient (write / accumulate), weight
     gradient incl. its split-K workspace -- once on the 128-row / 128x128 kernels (mode 0) and once with the 256x256 LDS-DMA cores and
@@ -142,10 +142,14 @@ def test_bf16_conv_launchers_stay_inside_their_outputs(edrl, dev, N, H, W, Ci, C
     neither fault nor leak into the outputs)."""
     ops, L = edrl.ops, edrl._lib
     P = L.ptr
-    switches(EDRL_BF16_V3=mode)
-    switches(EDRL_BF16_WGRAD_V3=mode)
-    switches(EDRL_BF16_C64=mode)
-    switches(EDRL_BF16_K64=mode)
+    if mode == "v3s":          # the 128x128 small-tile LDS-DMA core (conv_bf16_v3s.hip) forced wherever its geometry allows
+        switches(EDRL_BF16_V3S="2", EDRL_BF16_V3="0", EDRL_BF16_WGRAD_V3="0", EDRL_BF16_C64="0", EDRL_BF16_K64="0")
+    else:
+        switches(EDRL_BF16_V3S="0")
+        switches(EDRL_BF16_V3=mode)
+        switches(EDRL_BF16_WGRAD_V3=mode)
+        switches(EDRL_BF16_C64=mode)
+        switches(EDRL_BF16_K64=mode)
     bf = torch.bfloat16
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + Co)
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
