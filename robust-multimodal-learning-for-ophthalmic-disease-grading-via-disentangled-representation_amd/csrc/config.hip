@@ -17,7 +17,7 @@ static void load(EdrlConfig& c) {
   c.v3_fwd_kmin = env_int("EDRL_V3_FWD_KMIN", 256);
   c.v3_stagger = env_int("EDRL_V3_STAGGER", 0);
   c.bf16_v3s = env_int("EDRL_BF16_V3S", 1);
-  c.v3s_kmax = env_int("EDRL_V3S_KMAX", 512);
+  c.v3s_kmin = env_int("EDRL_V3S_KMIN", 1024);
   c.bf16_wgrad_v3 = env_int("EDRL_BF16_WGRAD_V3", 1);
   c.bf16_c64 = env_int("EDRL_BF16_C64", 1);
   c.bf16_k64 = env_int("EDRL_BF16_K64", 1);

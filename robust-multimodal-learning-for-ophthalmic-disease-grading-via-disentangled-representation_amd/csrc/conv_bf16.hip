@@ -514,14 +514,17 @@ static int launch_gather_bf16_impl(const __bf16* src, const __bf16* wm, __bf16* 
 }
 
 // EDRL_BF16_V3S: which plain-operand layers take the small-tile LDS-DMA core (conv_bf16_v3s.hip) instead of the 256 x 256 core or
-// the register-staged 128-row kernel.  Mode 2: every geometry it can run.  Auto (1): the HBM-leaning members -- K up to
-// EDRL_V3S_KMAX (512) with at least 128 output channels and enough rows to fill the chip twice over; the K-heavy 3x3 layers of
-// stages 3-4 keep the 256 x 256 core (1.1 PFLOP/s there: a 128 x 128 tile reads each LDS fragment for half as many MFMAs).
+// the register-staged 128-row kernel.  Mode 2: every geometry it can run.  Auto (1): the layers it measured faster on
+// (scripts/v3s_layer_bench.py, profiles/r05_v3s_layers_bf16_2048img.txt): 128 output channels with K >= EDRL_V3S_KMIN (1024) --
+// the 3x3 layers of the second residual stage, which the 256 x 256 core cannot take (NC % 256) and whose 36 K units amortise the
+// one-tile prologue: forward -6 %, data gradient -19 %, with the BatchNorm-backward epilogue -11 %.  On the short-K 1x1 layers it
+// LOSES to both existing kernels (`l3 1x1 256->1024` 0.65 ms against 0.50 on the persistent 256 x 256 core): with one tile per
+// workgroup the cold prologue of every 8-unit tile is exposed, and two workgroups per CU do not cover it.
 static bool gather_bf16_v3s_pick(const GatherGeom& g) {
   const int mode = edrl_cfg().bf16_v3s;
   if (mode == 0 || !gather_bf16_v3s_can(g)) return false;
   if (mode == 2) return true;
-  return g.Ktot <= edrl_cfg().v3s_kmax && g.NC >= 128 && (long)edrl_cdiv(g.M, 128) * (g.NC / 128) >= 1024;
+  return g.NC == 128 && g.Ktot >= edrl_cfg().v3s_kmin && g.step == 1 && (long)edrl_cdiv(g.M, 128) >= 1024;
 }
 
 template <int BN, bool DGRAD>

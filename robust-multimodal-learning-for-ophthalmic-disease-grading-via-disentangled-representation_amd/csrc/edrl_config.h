@@ -12,7 +12,7 @@ struct EdrlConfig {
   int v3_fwd_kmin;       // EDRL_V3_FWD_KMIN      the v3 forward takes K >= this (256 since the persistent form; 512 in round 3)
   int v3_stagger;        // EDRL_V3_STAGGER       1: staggered DMA issue of the two wave halves
   int bf16_v3s;          // EDRL_BF16_V3S         0 off | 1 auto | 2 wherever the geometry allows: 128x128 LDS-DMA core, two workgroups per CU (conv_bf16_v3s.hip)
-  int v3s_kmax;          // EDRL_V3S_KMAX         (auto) the small-tile core takes plain layers with K <= this
+  int v3s_kmin;          // EDRL_V3S_KMIN         (auto) the small-tile core takes 128-output-channel layers with K >= this (1024: the 3x3 layers of stage 2)
   int bf16_wgrad_v3;     // EDRL_BF16_WGRAD_V3    0 | 1 | 2: 256x256 LDS-DMA weight-gradient core
   int bf16_c64;          // EDRL_BF16_C64         0 | 1 | 2: weight-stationary 64 -> 64 3x3 kernel
   int bf16_k64;          // EDRL_BF16_K64         0 | 1 | 2: streaming expanding-1x1 kernel
