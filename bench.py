@@ -54,6 +54,10 @@ CONFIGS = {
 RECOMPUTE = {"C3"}     # configs that run with args.activation_recompute (encoders.ResNetTrunk.recompute_out)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense, 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
+# fp32 contractions of the shipped library (edrl_f32_contraction_split() == 1): six exact bf16 products per fp32 product on the bf16
+# MFMA, so the matrix pipe's ceiling for ALGORITHMIC fp32 FLOPs is the bf16 dense peak / 6
+PEAK_F32_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+F32_SPLIT = None     # set in main() from the loaded library
 
 
 PMC_FAMILIES = {   # bench timer key -> kernel families of scripts/pmc_traffic.py whose launches it brackets
@@ -94,7 +98,7 @@ def roofline_blocks(timer, enc_dtype, dt, steps, cfg, desc):
     roof = None
     if dom:
         avg_ms = dom["ms"] / dom["launches"]
-        peak = PEAK_BF16_MFMA_TFLOPS if enc_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if enc_dtype == "bf16" else (PEAK_F32_SPLIT_TFLOPS if F32_SPLIT else PEAK_F32_MFMA_TFLOPS)
         # algorithmic bytes per step of everything rocprofv3 files under this family: the head's Linear layers run the same kernels
         lin = ks.get("linear_gather") if enc_dtype != "bf16" else None
         alg_step = (dom.get("bytes", 0.0) + (lin.get("bytes", 0.0) if lin else 0.0)) / steps
@@ -104,7 +108,9 @@ def roofline_blocks(timer, enc_dtype, dt, steps, cfg, desc):
                        "HBM-bound and fused-BatchNorm layers) + conv3x3_c64_bf16_kernel / conv1x1_k64_bf16_kernel (weight-stationary: "
                        "64-channel 3x3 and expanding 1x1 layers of stages 1-2)"
                        if enc_dtype == "bf16" else
-                       "conv_gather_f32_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)"),
+                       ("conv_gather_f32_v2_kernel (implicit-GEMM conv fwd+dgrad; fp32 operands split exactly into three bf16 planes while "
+                        "staged, six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation)" if F32_SPLIT else
+                        "conv_gather_f32_v2_kernel (implicit-GEMM conv fwd+dgrad, v_mfma_f32_32x32x2_f32)")),
             "bound": "mfma", "achieved": round(dom["tflops"], 3), "peak": peak,
             "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
             "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
@@ -142,6 +148,11 @@ def roofline_blocks(timer, enc_dtype, dt, steps, cfg, desc):
             roof["per_step"].update(measured_hbm_bytes=round(pm["bytes_per_step"]),
                                     measured_over_algorithmic=round(pm["bytes_per_step"] / alg_step, 3) if alg_step else None,
                                     rocprofv3_launches=pm["launches_per_step"])
+        if enc_dtype != "bf16" and F32_SPLIT:
+            roof["peak_note"] = ("algorithmic fp32 FLOP/s against the dense bf16 MFMA peak / 6 (2516.6 / 6: six bf16 products per fp32 "
+                                 "product); the fp32 MFMA's own peak is 157.3 TFLOP/s (`frac_of_fp32_mfma_peak`), what the fp32-MFMA "
+                                 "build of the same sources reaches is in `f32_mfma_leg`")
+            roof["frac_of_fp32_mfma_peak"] = round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
         if enc_dtype == "bf16":
             roof["note"] = ("priced against the dense bf16 MFMA peak; at bf16 most ResNet-50 conv layers are "
                             "HBM-bound (50-250 FLOP/B against a ~450 FLOP/B ridge), only the 3x3 layers of "
@@ -179,12 +190,15 @@ def main():
     ap.add_argument("--no-recompute-leg", action="store_true", help="skip the extra timed region with args.activation_recompute")
     ap.add_argument("--no-anchor-leg", action="store_true", help="skip the N = 1 timing of the C3 per-GPU workload (scale_anchor)")
     ap.add_argument("--no-bf16-legs", action="store_true", help="skip the C2 / C4 legs of the default N = 1 line (bf16_leg, c4_leg)")
+    ap.add_argument("--no-f32-mfma-leg", action="store_true", help="skip the child run of this workload on libedrl_hip_f32mfma.so (f32_mfma_leg)")
     a = ap.parse_args()
 
     import gc
     import torch
     import torch.distributed as dist
     import edrl_amd
+    global F32_SPLIT
+    F32_SPLIT = bool(edrl_amd._lib.lib().fn["edrl_f32_contraction_split"]())
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -406,6 +420,30 @@ def main():
         c4_leg["unit"] = "samples/s"
         c4_leg["note"] = "per-GPU shape of the 8-GPU configuration (B=4 per GPU) on one GPU; the 8-rank run is the driver's"
     drop()
+    # The same workload on the fp32-MFMA build of the same sources (v_mfma_f32_32x32x2_f32 contractions): a child process -- a
+    # process binds one library -- started after this one has given its device memory back.  Never `value`.
+    f32_mfma_leg = None
+    if default_line and F32_SPLIT and not a.no_f32_mfma_leg:
+        import subprocess
+        mlib = os.path.join(os.path.dirname(os.path.abspath(edrl_amd._lib.LIB_PATH)), "libedrl_hip_f32mfma.so")
+        if os.path.exists(mlib):
+            k5 = min(a.steps, 5)
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", a.config, "--steps", str(k5), "--warmup", "2", "--no-cpu-baseline",
+                   "--no-recompute-leg", "--no-anchor-leg", "--no-bf16-legs", "--no-f32-mfma-leg"]
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, EDRL_LIB_PATH=mlib), capture_output=True, text=True, timeout=300)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and line:
+                    d = json.loads(line[-1])
+                    f32_mfma_leg = {"library": "libedrl_hip_f32mfma.so (csrc/conv_gemm.hip compiled -DEDRL_F32_SPLIT=0: fp32 contractions on "
+                                               "v_mfma_f32_32x32x2_f32)", "command": "EDRL_LIB_PATH=<package>/libedrl_hip_f32mfma.so python " + " ".join(cmd[1:]),
+                                    "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                                    "in_order": {k: d["in_order"][k] for k in ("value", "ms_per_step")} if "in_order" in d else None,
+                                    "roofline": {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")} if "roofline" in d else None}
+                else:
+                    f32_mfma_leg = {"error": (r.stderr or r.stdout)[-400:]}
+            except subprocess.TimeoutExpired:
+                f32_mfma_leg = {"error": "timed out"}
 
     if rank == 0:
         value = B * world * a.steps / dt
@@ -419,6 +457,12 @@ def main():
             "final_loss": loss,
             "peak_mem_GiB": round(peak_primary / 2 ** 30, 2),
         }
+        if True:
+            res["fp32_contractions"] = (
+                "exact bf16x3 split: every fp32 operand element = three bf16 values exactly, each fp32 product = six exact bf16 "
+                "products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error against fp64 at or below the fp32 MFMA's on every "
+                "ResNet-50 layer class (tests/test_gpu_kernels.py::test_f32_split_at_least_as_accurate_as_fp32_mfma); storage, "
+                "BatchNorm, reductions, optimiser: fp32" if F32_SPLIT else "v_mfma_f32_32x32x2_f32 (fp32-MFMA build)")
         res["execution"] = ("two views on two HIP streams (product default; bit-identical to the in-order step)" if overlapped
                             else "in order on one stream (--in-order / EDRL_VIEW_STREAM=0)")
         if timer is not None:
@@ -441,6 +485,8 @@ def main():
             res["bf16_leg"] = bf16_leg
         if c4_leg is not None:
             res["c4_leg"] = c4_leg
+        if f32_mfma_leg is not None:
+            res["f32_mfma_leg"] = f32_mfma_leg
         if world > 1:
             res["per_rank_ms_per_step"] = {"min": min(per_rank), "max": max(per_rank), "ranks": per_rank,
                                            "note": "each rank's own time for the K timed steps (before the closing barrier) / K"}

@@ -477,6 +477,12 @@ int edrl_conv3d_ndhwc_wgrad_f32(const float* dy, const float* x, float* dw, floa
  * rocprofv3's.
  * The library allocates nothing: the slab the split workgroups hand their accumulators over in is the caller's, see below. */
 long edrl_gather_launch_count(void);
+/* How this build of the library multiplies fp32 operands in the conv / Linear contractions (forward, data and weight gradient):
+ * 1 = every fp32 operand element is split exactly into three bf16 values and the product formed from six exact bf16 products on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (libedrl_hip.so; csrc/conv_gemm.hip EDRL_F32_SPLIT: error against fp64 at or
+ * below the fp32 MFMA's, tests/test_gpu_kernels.py); 0 = v_mfma_f32_32x32x2_f32 (libedrl_hip_f32mfma.so, same sources).
+ * Replaces nothing in the reference (torch's conv2d / linear have one fp32 path); bench.py reports it. */
+int edrl_f32_contraction_split(void);
 
 /* K-split workspace of the fp32 gather family (csrc/conv_gemm.hip gather_ksplit_plan).  The caller registers ONE slab of at least
  * edrl_gather_ksplit_workspace_bytes() (16 MiB, 16-byte aligned) per (current HIP device, stream) it launches the family on; the

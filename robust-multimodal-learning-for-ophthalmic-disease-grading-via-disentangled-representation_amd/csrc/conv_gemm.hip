@@ -34,6 +34,77 @@
 #ifndef EDRL_F32_SWZ
 #define EDRL_F32_SWZ 1      // 0: the padded [row][BKT + 4] K-loop image of rounds 1-4 (A/B builds: make CXXFLAGS+=-DEDRL_F32_SWZ=0)
 #endif
+// EDRL_F32_SPLIT: fp32 contractions on the bf16 matrix pipe.  Each fp32 operand element is split (round to nearest) into three
+// bf16 values a = a0 + a1 + a2 EXACTLY (8 + 8 + 8 mantissa bits with signed remainders), and a*b is formed as the six products
+// a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: every product is exact in
+// fp32, the three dropped ones (a1b2, a2b1, a2b2) are below 2^-25 |ab| -- under the rounding of an fp32 multiply -- and the
+// accumulator sees 6 roundings per 16 k where the fp32 MFMA path (v_mfma_f32_32x32x2_f32) sees 8.  Why: gfx950 runs the bf16
+// MFMA at 16x the rate of the fp32 MFMA (2.5 PFLOP/s against 157 TFLOP/s), so six bf16 products cost 192 matrix-pipe cycles per
+// 16 k of a 32 x 32 tile against 512 -- and the bf16 MFMA co-executes with the VALU, which the fp32 MFMA does not.
+// Not reproduced: an operand element with |a| >= 2^128 (1 - 2^-9) (rounds to a bf16 infinity) or +-inf gives NaN where the fp32
+// MFMA gives +-inf; below |a| ~ 2^-110 the middle / low planes are bf16 denormals (the element is then good to its high plane,
+// 2^-9 relative, where the matrix pipe flushes them).  tests/test_gpu_kernels.py: exact reconstruction over 28 decades, exact
+// integer results, error against fp64 next to the fp32-MFMA build's.
+#ifndef EDRL_F32_SPLIT
+#define EDRL_F32_SPLIT 1      // 0: fp32 MFMA (libedrl_hip_f32mfma.so is this file compiled with -DEDRL_F32_SPLIT=0)
+#endif
+#ifndef EDRL_F32_SPLIT_OCC
+#define EDRL_F32_SPLIT_OCC 3    // workgroups per CU of the split kernels (48 KiB of LDS each at 128 x 128)
+#endif
+// workgroups per CU of a gather-kernel variant: the split K loop keeps two register sets of operand loads in flight
+constexpr int edrl_gather_occ(int bkt, bool fast, bool buf, int atr, int occ) {
+  if (!(EDRL_F32_SPLIT != 0 && bkt == 16 && fast && buf)) return occ;
+  const int cap = atr == 2 ? 2 : EDRL_F32_SPLIT_OCC;
+  return occ > cap ? cap : occ;
+}
+typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sp_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sp_u32x2 __attribute__((ext_vector_type(2)));
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+// exact three-way split of four fp32 values into bf16 planes (round to nearest even at every level; remainders are exact)
+__device__ __forceinline__ void edrl_split3(sp_f32x4 v, sp_u32x2& p0, sp_u32x2& p1, sp_u32x2& p2) {
+  sp_bf16x4 h, m, l;
+  sp_f32x4 r, r2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = v[e] - (float)h[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m[e] = (__bf16)r[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r2[e] = r[e] - (float)m[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) l[e] = (__bf16)r2[e];
+  p0 = __builtin_bit_cast(sp_u32x2, h);
+  p1 = __builtin_bit_cast(sp_u32x2, m);
+  p2 = __builtin_bit_cast(sp_u32x2, l);
+}
+// Weight-gradient image of the split path: per plane [16 pixels][W channels] bf16, unpadded; the 64-byte granule index of a row
+// is XORed with a function of the pixel row so that the four rows of a transposing-read block (ds_read_b64_tr_b16: 4 pixels x 16
+// channels per 16-lane group, two groups side by side) fall on four different 64-byte bank ranges, and so do the two pixel rows a
+// 32-lane store pass touches.
+template <int W>
+__device__ __forceinline__ int edrl_wsplit_off(int row, int col) {          // byte offset of (pixel row, channel col) in a plane
+  static_assert(W == 64 || W == 128, "tile widths of the weight-gradient kernel");
+  const int gsw = W == 128 ? ((((row & 1) << 1) | ((row >> 1) & 1))) : ((row >> 1) & 1);
+  return row * (W * 2) + (((col >> 5) ^ gsw) << 6) + ((col & 31) << 1);
+}
+typedef short sp_s16x4 __attribute__((ext_vector_type(4)));
+// 8-deep fragment (pixels pix0 .. pix0 + 7 of channel col0 + (lane & 15)) of one plane: two transposing reads
+template <int W>
+__device__ __forceinline__ sp_bf16x8 edrl_wsplit_frag(const char* plane, int pix0, int col0, int lane) {
+  const int g16 = lane & 15, q = g16 >> 2, p4 = g16 & 3;
+  const char* a0 = plane + edrl_wsplit_off<W>(pix0 + q, col0 + 4 * p4);
+  const sp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sp_s16x4*)(a0));
+  const sp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sp_s16x4*)(a0 + 4 * (W * 2)));
+  union { struct { sp_s16x4 l, h; } s; sp_bf16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+constexpr int edrl_wgrad_occ(int bkt, bool fastld, int occ) {
+  if (!(EDRL_F32_SPLIT != 0 && bkt == 16 && fastld)) return occ;
+  return occ > EDRL_F32_SPLIT_OCC ? EDRL_F32_SPLIT_OCC : occ;
+}
 
 template <int BM, int BN, bool DGRAD, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_gather_f32_kernel(
@@ -298,7 +369,8 @@ __device__ __forceinline__ u32x2 edrl_pack_bf16x4(f32x4 v) {
 // geometry over a depth-reversed, class-compacted weight matrix (no kernel code of its own).
 template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
           bool OUT16 = false, bool VOL = false>
-__global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
+__global__ __launch_bounds__(256, edrl_gather_occ(BKT, FAST, BUF, ATR, OCC))
+void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherSplit S, GatherFuse F) {
   static_assert(ATR == 0 || BUF, "operand transforms ride on the buffer-descriptor path");
@@ -315,6 +387,10 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
   // [row][BKT + 4] image of rounds 1-4 was conflict-free on the reads but 2-way on one slot of every store group
   // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.30 over the C1 step, profiles/r04_pmc_traffic_c1.json).
   constexpr bool SWZ = EDRL_F32_SWZ != 0 && BKT == 16 && FAST;
+  // SPL (EDRL_F32_SPLIT, top of the file): the K-loop image holds three bf16 planes per operand, [plane][row][16 k] with 32-byte
+  // rows; the 16-byte half of a row (k 0-7 / 8-15) sits at half ^ ((row >> 4) & 1): the ds_read_b128 lane groups (rows {0-3,
+  // 12-15, 20-27} / {4-11, 16-19, 28-31} of one half) then cover the sixteen 16-byte slots of the 256-byte bank window once.
+  constexpr bool SPL = EDRL_F32_SPLIT != 0 && BKT == 16 && FAST && BUF;
   constexpr int LDKT = SWZ ? BKT : BKT + 4;
   constexpr int KQ = BKT / 4;            // float4 columns per row of a K tile
   constexpr int RPP = 256 / KQ;          // rows covered by one staging piece
@@ -590,15 +666,108 @@ __global__ __launch_bounds__(256, OCC) void conv_gather_f32_v2_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int li = lane & 31, lh = lane >> 5;
+  if constexpr (SPL) {
+    // Split K loop.  The matrix-pipe chain of a K tile is 24 MFMAs x 32 cycles -- shorter than a memory latency -- so the operand
+    // loads run TWO tiles ahead in two register sets: iteration t issues the loads of tile t + 2 into set t & 1, multiplies tile t
+    // out of LDS buffer t & 1, and (transforms,) splits and stores tile t + 1 from set (t + 1) & 1 into the other buffer.
+    f32x4 qa[2][A_LD], qb[2][B_LD], qa2[ATR == 2 ? 2 : 1][A_LD];
+    bool qok[2][A_LD];
+    auto sp_load = [&](auto PC) {
+      constexpr int P = decltype(PC)::value;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        qa[P][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)aoff[i], 0, 0));
+        if constexpr (ATR == 2) qa2[P][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, (int)aoff[i], 0, 0));
+        if constexpr (ATR != 0 && MASK) qok[P][i] = (int)aoff[i] >= 0;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) qb[P][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)boff[i], 0, 0));
+    };
+    const int sq = tid % KQ;
+    const int sso = r0 * 32 + ((((sq >> 1) ^ (r0 >> 4)) & 1) << 4) + ((sq & 1) << 3);   // (rows r0 + 64 i: bit 4 of the row = bit 4 of r0)
+    auto sp_finish = [&](auto PC, int buf) {
+      constexpr int P = decltype(PC)::value;
+      char* a = (char*)smem + buf * (BM * 96) + sso;
+      char* b = (char*)smem + 2 * BM * 96 + buf * (BN * 96) + sso;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        f32x4 v = qa[P][i];
+        if constexpr (ATR == 1) v = edrl_bn_relu2(v, tp0, tp1);
+        if constexpr (ATR == 2) v = edrl_bn_bwd_dx2(v, qa2[ATR == 2 ? P : 0][i], tp0, tp1, tp2);
+        if constexpr (ATR != 0 && MASK) v = qok[P][i] ? v : zero4;
+        sp_u32x2 p0, p1, p2;
+        edrl_split3(v, p0, p1, p2);
+        char* d = a + RPP * i * 32;
+        *reinterpret_cast<sp_u32x2*>(d) = p0;
+        *reinterpret_cast<sp_u32x2*>(d + BM * 32) = p1;
+        *reinterpret_cast<sp_u32x2*>(d + 2 * BM * 32) = p2;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        sp_u32x2 p0, p1, p2;
+        edrl_split3(qb[P][i], p0, p1, p2);
+        char* d = b + RPP * i * 32;
+        *reinterpret_cast<sp_u32x2*>(d) = p0;
+        *reinterpret_cast<sp_u32x2*>(d + BN * 32) = p1;
+        *reinterpret_cast<sp_u32x2*>(d + 2 * BN * 32) = p2;
+      }
+    };
+    const int hs = ((lh ^ (li >> 4)) & 1) << 4;
+    auto sp_iter = [&](auto PC) {
+      constexpr int P = decltype(PC)::value;
+      load_params();                    // of tile t + 1 (the decode state is one tile ahead of the LDS image)
+      advance();                        // -> tile t + 2
+      sp_load(PC);
+      __builtin_amdgcn_sched_barrier(0);
+      const char* pa = (const char*)smem + P * (BM * 96) + (wm0 + li) * 32 + hs;
+      const char* pb = (const char*)smem + 2 * BM * 96 + P * (BN * 96) + (wn0 + li) * 32 + hs;
+      sp_bf16x8 fa[3][TM], fb[2][TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const sp_bf16x8*>(pb + j * 1024);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const sp_bf16x8*>(pa + p * (BM * 32) + i * 1024);
+      // weight plane q meets pixel planes 0 .. 2 - q: 3 + 2 + 1 = 6 products per element pair
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+        if (q + 1 < 3) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const sp_bf16x8*>(pb + (q + 1) * (BN * 32) + j * 1024);
+        }
+#pragma unroll
+        for (int p = 2 - q; p >= 0; --p)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      }
+      sp_finish(std::integral_constant<int, P ^ 1>{}, P ^ 1);
+      __syncthreads();
+    };
+    sp_load(std::integral_constant<int, 0>{});
+    load_params();
+    sp_finish(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+    advance();
+    sp_load(std::integral_constant<int, 1>{});
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      sp_iter(std::integral_constant<int, 0>{});
+      if (kt + 1 < kt1) sp_iter(std::integral_constant<int, 1>{});
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) load_piece(i);
   load_params();
   transform_tile();
   store_tile(0);
   __syncthreads();
+  }
 
-  const int li = lane & 31, lh = lane >> 5;
-  for (int kt = kt0; kt < kt1; ++kt) {
+  for (int kt = kt0; kt < (SPL ? kt0 : kt1); ++kt) {
     const int buf = (kt - kt0) & 1;
     advance();   // decode state of tile kt+1 (past the end: kvalid is false and the pieces load zeros)
     // (SWZ: fragment rows wm0 + li + 32 i have (row >> 2) & 3 = (li >> 2) & 3; chunk lh + 2 kc of the row sits at chunk ^ that)
@@ -1022,7 +1191,8 @@ static int launch_gather_v2(const float* src, const float* wm, float* dst, const
   }
   if (nblk <= 0) return 0;
   if (nblk > 0x7fffffffL) return EDRL_EINVAL;
-  const size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
+  constexpr bool SPL = EDRL_F32_SPLIT != 0 && BKT == 16 && FAST && BUF;
+  const size_t lds = SPL ? (size_t)2 * (BM + BN) * 96 : (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
   auto kern = conv_gather_f32_v2_kernel<BM, BN, DGRAD, BKT, OCC, FAST, BUF, ATR, EPI, MASK, OUT16, VOL>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1334,7 +1504,7 @@ struct WgradFuse {
 // tap 0 and its wrap at a sample boundary), the depth tap of a column is a per-thread constant like its (kh, kw).
 template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true,
           bool DY16 = false, bool VOL = false>
-__global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
+__global__ __launch_bounds__(256, edrl_wgrad_occ(BKT, FASTLD, OCC)) void conv_wgrad_f32_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g, WgradFuse F) {
   static_assert((DYT == 0 && XT == 0) || FASTLD, "operand transforms ride on the buffer-descriptor path");
   static_assert(!VOL || (FASTLD && DYT == 0 && XT == 0 && !DY16), "depth taps: plain buffer-load path only");
@@ -1345,6 +1515,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
   constexpr int A_LD = (BM * BKT / 4) / 256, B_LD = (BN * BKT / 4) / 256;
   constexpr int AC4 = BM / 4, BC4 = BN / 4;
   constexpr int LDA = BM + 4, LDB = BN + 4;
+  // SPLW (EDRL_F32_SPLIT, top of the file): three bf16 planes per operand, [buffer][plane][16 pixels][channels]
+  constexpr bool SPLW = EDRL_F32_SPLIT != 0 && BKT == 16 && FASTLD;
+  constexpr int PLA = 16 * BM * 2, PLB = 16 * BN * 2;      // bytes per plane
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BK][LDA]
   float* Bs = smem + 2 * BKT * LDA;     // [2][BK][LDB]
@@ -1591,6 +1764,29 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     }
   };
   auto store_tile = [&](int buf) {
+    if constexpr (SPLW) {
+      char* a = (char*)smem + buf * (3 * PLA);
+      char* b = (char*)smem + 2 * (3 * PLA) + buf * (3 * PLB);
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        sp_u32x2 p0, p1, p2;
+        edrl_split3(a_st[i], p0, p1, p2);
+        char* d = a + edrl_wsplit_off<BM>((tid + 256 * i) / AC4, ac4 * 4);
+        *reinterpret_cast<sp_u32x2*>(d) = p0;
+        *reinterpret_cast<sp_u32x2*>(d + PLA) = p1;
+        *reinterpret_cast<sp_u32x2*>(d + 2 * PLA) = p2;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        sp_u32x2 p0, p1, p2;
+        edrl_split3(b_st[i], p0, p1, p2);
+        char* d = b + edrl_wsplit_off<BN>(tid >> 4, ((tid & 15) + 16 * i) * 4);
+        *reinterpret_cast<sp_u32x2*>(d) = p0;
+        *reinterpret_cast<sp_u32x2*>(d + PLB) = p1;
+        *reinterpret_cast<sp_u32x2*>(d + 2 * PLB) = p2;
+      }
+      return;
+    }
     float* a = As + buf * BKT * LDA;
     float* b = Bs + buf * BKT * LDB;
 #pragma unroll
@@ -1645,6 +1841,41 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_f32_kernel(
     for (int t = t_begin; t < t_end; ++t) {
       const int buf = (t - t_begin) & 1;
       if (t + 1 < t_end) load_tile(t + 1);
+      if constexpr (SPLW) {
+        __builtin_amdgcn_sched_barrier(0);
+        const char* pa = (const char*)smem + buf * (3 * PLA);
+        const char* pb = (const char*)smem + 2 * (3 * PLA) + buf * (3 * PLB);
+        const int cg = 16 * ((lane >> 4) & 1);
+        sp_bf16x8 fa[3][TM], fb[2][TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = edrl_wsplit_frag<BN>(pb, 8 * lh, wn0 + 32 * j + cg, lane);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[p][i] = edrl_wsplit_frag<BM>(pa + p * PLA, 8 * lh, wm0 + 32 * i + cg, lane);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {       // im2col plane q meets gradient planes 0 .. 2 - q
+          const int cur = q & 1, nxt = cur ^ 1;
+          if (q + 1 < 3) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[nxt][j] = edrl_wsplit_frag<BN>(pb + (q + 1) * PLB, 8 * lh, wn0 + 32 * j + cg, lane);
+          }
+#pragma unroll
+          for (int p = 2 - q; p >= 0; --p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < t_end) {
+#pragma unroll
+          for (int el = 0; el < EL; ++el) transform_piece(el);
+          store_tile(buf ^ 1);
+        }
+        __syncthreads();
+        continue;
+      }
       const float* a = As + buf * BKT * LDA + wm0 + li;
       const float* b = Bs + buf * BKT * LDB + wn0 + li;
       // software pipeline over the k-steps: the fragments of step s+1 are requested BEFORE the TM*TN MFMAs of step s
@@ -1740,7 +1971,8 @@ template <int BM, int BN, bool VEC, bool FASTLD = false, int DYT = 0, int XT = 0
           bool VOL = false>
 static int launch_wgrad(const float* dy, const float* x, float* part, const WgradGeom& g, int splits,
                         hipStream_t st, const WgradFuse* fuse = nullptr) {
-  const size_t lds = (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
+  constexpr bool SPLW = EDRL_F32_SPLIT != 0 && FASTLD;
+  const size_t lds = SPLW ? (size_t)2 * 3 * 16 * (BM + BN) * 2 : (size_t)2 * WG_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
   auto kern = conv_wgrad_f32_kernel<BM, BN, VEC, WG_BK, (XT ? WG_OCC_FUSED : WG_OCC), FASTLD, DYT, XT, MASKX, DY16, VOL>;
   WgradFuse F;
   if (fuse) F = *fuse; else memset(&F, 0, sizeof(F));
@@ -1798,6 +2030,8 @@ extern "C" {
 
 // Kernels of the fp32 implicit-GEMM gather family launched by this process so far (diagnostic: bench.py's per-launch averages).
 long edrl_gather_launch_count(void) { return g_gather_launches.load(); }
+// 1: this build forms fp32 products as exact bf16x3 splits on the bf16 MFMA (EDRL_F32_SPLIT); 0: fp32 MFMA (libedrl_hip_f32mfma.so)
+int edrl_f32_contraction_split(void) { return EDRL_F32_SPLIT != 0 ? 1 : 0; }
 // K-split slab of the fp32 gather family: caller-owned, registered per (current device, stream); see gather_slab_locked above.
 size_t edrl_gather_ksplit_workspace_bytes(void) { return GATHER_SLAB_BYTES; }
 int edrl_gather_ksplit_set_workspace(float* slab, size_t bytes, hipStream_t st) {
@@ -1921,6 +2155,17 @@ int edrl_conv2d_nhwc_fwd_stats_f32_obf16(const float* x, const float* w, void* y
   g.h0 = g.w0 = 0; g.step = 1; g.OHs = Ho; g.OWs = Wo;
   g.kh0 = g.kw0 = 0; g.kstep = 1; g.KHs = KH; g.KWs = KW; g.Kfull = g.Ktot; g.sshift = 0;
   g.stat_part = stat_part; g.stat_shift = nullptr;
+  {   // the space-to-depth stem (16 channels per tap) takes the same buffer-descriptor kernel as its fp32-output twin
+      // (dispatch_gather): same tiles, same K loop, so the two outputs differ by the final rounding only
+    const long ohw = (long)Ho * Wo;
+    const bool fast = (Ci % 16 == 0) && edrl_cfg().gather_buf != 0 && edrl_cfg().gather_variant != 0 && edrl_cfg().gather_variant != 3 &&
+                      (128 / ohw + 2) * Hi * Wi * Ci * 4 < (1L << 31) && (long)Co * g.Kfull * 4 < (1L << 31);
+    if (fast) {
+      if (Co <= 64)
+        return launch_gather_v2<128, 64, false, 16, 4, true, true, 0, 0, true, true>(x, w, (float*)y_bf16, nullptr, nullptr, g, st);
+      return launch_gather_v2<128, 128, false, 16, 4, true, true, 0, 0, true, true>(x, w, (float*)y_bf16, nullptr, nullptr, g, st);
+    }
+  }
   if (Co <= 64)
     return launch_gather_v2<128, 64, false, 16, 3, false, false, 0, 0, true, true>(x, w, (float*)y_bf16, nullptr, nullptr, g, st);
   return launch_gather_v2<128, 128, false, 16, 3, false, false, 0, 0, true, true>(x, w, (float*)y_bf16, nullptr, nullptr, g, st);

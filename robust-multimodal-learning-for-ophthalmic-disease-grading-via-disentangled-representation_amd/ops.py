@@ -51,12 +51,20 @@ class KernelTimer:
 
     PEAK_BW = 8.0e12                                    # HBM3E, MI355X_MICROARCH.md
     PEAK_F32, PEAK_BF16 = 157.3e12, 2.5e15              # dense MFMA peaks
+    _peak_f32 = None
+
+    def peak_f32(self):
+        """Matrix-pipe ceiling for algorithmic fp32 FLOPs of the loaded library: bf16 dense peak / 6 when it forms fp32 products as
+        bf16x3 splits (edrl_f32_contraction_split), the fp32 MFMA's peak otherwise."""
+        if KernelTimer._peak_f32 is None:
+            KernelTimer._peak_f32 = 2516.6e12 / 6.0 if L.lib().fn["edrl_f32_contraction_split"]() else self.PEAK_F32
+        return KernelTimer._peak_f32
 
     def add(self, kind, flops, e0, e1, kernels=1, nbytes=0.0):
         r = self.records.setdefault(kind, [0.0, [], 0, 0.0, 0.0])
         r[0] += flops
         # speed-of-light time of THIS call: whichever of its algorithmic flops / bytes binds
-        t_f = flops / (self.PEAK_BF16 if kind.endswith("bf16") else self.PEAK_F32)
+        t_f = flops / (self.PEAK_BF16 if kind.endswith("bf16") else self.peak_f32())
         t_b = nbytes / self.PEAK_BW
         r[1].append((e0, e1, t_b > t_f, flops, nbytes))
         r[2] += kernels
