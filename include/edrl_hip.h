@@ -255,6 +255,9 @@ int edrl_bn_bwd_reduce_bf16(const void* dout, const unsigned char* relu_mask, co
 /* d_raw (bf16) = A*g + nK2*x + C2 with bcoef [4][C]: the BatchNorm-backward apply step as a standalone pass, for a conv that takes
  * d_raw on the plain kernels inside an otherwise fused block (the 3x3 layer of a bf16 bottleneck block). */
 int edrl_bn_draw_bf16(const void* g, const void* x, const float* bcoef, void* d_raw, long M, int C, hipStream_t stream);
+/* The same pass over fp32 tensors (C % 4 == 0): the fp32 trunk's units that run on the plain kernels (encoders._K32: the 3x3
+ * layer of a fused bottleneck block, the blocks above EDRL_F32_FUSE_MAXPLANES). */
+int edrl_bn_draw_f32(const float* g, const float* x, const float* bcoef, float* d_raw, long M, int C, hipStream_t stream);
 
 /* Mixed-precision BatchNorm apply / backward and max-pool of the bf16 (C2) trunk: raw_bf16 / act_bf16 give the storage type
  * (0 fp32, 1 bf16) of the raw conv output (+ its gradient) and of the activated tensors (+ their gradients); statistics,

@@ -1962,6 +1962,51 @@ int edrl_bn_bwd_reduce_bf16(const void* dout, const unsigned char* relu_mask, co
   return 0;
 }
 
+// the same pass over fp32 tensors (float4 per lane, four in flight): the fp32 trunk's plain-kernel units (encoders._K32.mid_sep / wide)
+__global__ __launch_bounds__(256) void bn_draw_f4_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                         const float* __restrict__ bcoef, float* __restrict__ out, long M, int C) {
+  const int C4 = C >> 2;
+  const long total = M * C4;
+  const long cstride = (long)gridDim.x * 1024;
+  for (long base = (long)blockIdx.x * 1024; base < total; base += cstride) {
+    f32x4 gv[4], xv[4];
+    long idx[4];
+    int cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = base + u * 256 + threadIdx.x;
+      idx[u] = i;
+      if (i < total) {
+        const long r = i / C4;
+        cc[u] = (int)(i - r * C4) * 4;
+        gv[u] = *reinterpret_cast<const f32x4*>(g + r * C + cc[u]);
+        xv[u] = *reinterpret_cast<const f32x4*>(x + r * C + cc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (idx[u] < total) {
+        const f32x4 A = *reinterpret_cast<const f32x4*>(bcoef + cc[u]);
+        const f32x4 nK2 = *reinterpret_cast<const f32x4*>(bcoef + (long)C + cc[u]);
+        const f32x4 C2 = *reinterpret_cast<const f32x4*>(bcoef + 2 * (long)C + cc[u]);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = __builtin_fmaf(nK2[e], xv[u][e], __builtin_fmaf(A[e], gv[u][e], C2[e]));
+        *reinterpret_cast<f32x4*>(out + idx[u] * 4) = d;
+      }
+    }
+  }
+}
+
+// d_raw = A*g + nK2*x + C2 with bcoef [4][C]; g, x, d_raw dense [M][C] fp32, C % 4 == 0: the same fma order as the operand
+// transform of the fused conv kernels (edrl_bn_bwd_dx2 in conv_gemm.hip), so a unit gives the same d_raw either way.
+int edrl_bn_draw_f32(const float* g, const float* x, const float* bcoef, float* d_raw, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || (C & 3) || !g || !x || !bcoef || !d_raw) return EDRL_EINVAL;
+  hipLaunchKernelGGL(bn_draw_f4_kernel, dim3(bn_apply_grid(M * (C / 4))), dim3(256), 0, st, g, x, bcoef, d_raw, M, C);
+  EDRL_LAUNCH_CHECK();
+  return 0;
+}
+
 // d_raw (bf16) = A*g + nK2*x + C2 with bcoef [4][C] (edrl_bn_bwd_finalize_partials_f32); g, x, d_raw dense [M][C] bf16, C % 8 == 0.
 int edrl_bn_draw_bf16(const void* g, const void* x, const float* bcoef, void* d_raw, long M, int C, hipStream_t st) {
   if (M <= 0 || C <= 0 || (C & 7) || !g || !x || !bcoef || !d_raw) return EDRL_EINVAL;

@@ -901,7 +901,7 @@ void conv_gather_f32_v2_kernel(
     // every other combination takes the general loop below.
     const bool lean_flags = EPI == 0 ? !accum
                           : EPI == 1 ? (!accum && !F.ep_mask && (g.flags & GF_EPI_RELU))
-                                     : (accum && F.ep_mask != nullptr);
+                                     : (F.ep_mask != nullptr);       // (EPI 2: sign bytes; accumulate or not -- a uniform branch)
     const bool lean = m0 + BM <= g.M && !bias && !mul && !relu && lean_flags &&
                       (!(DGRAD && g.step > 1) || (g.flags & GF_LEAN_STRIDED));
     if (lean) {
@@ -966,7 +966,7 @@ void conv_gather_f32_v2_kernel(
             for (int t = 0; t < NT; ++t) {
               xr[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox(t), so(t, RPP2 * ldx4), 0));
               if constexpr (EPI == 2) {
-                old[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)od(t), so(t, RPP2 * ldd4), 0));
+                if (accum) old[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)od(t), so(t, RPP2 * ldd4), 0));
                 kb[t] = __builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)ok(t), so(t, RPP2 * nq), 0);
               }
             }
@@ -999,7 +999,7 @@ void conv_gather_f32_v2_kernel(
                 for (int e = 0; e < 4; ++e) v[e] = pre[e] > 0.f ? v[e] : 0.f;
               }
               if constexpr (EPI == 2) {
-                v += old[t];
+                if (accum) v += old[t];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {    // bit e of the sign byte -> all-ones / zero (1-bit signed field extract), AND
                   const float ve = v[e];         // (a copy: bit_cast applied to the vector element itself reads element 0)
@@ -2540,7 +2540,8 @@ long edrl_conv_dgrad_bn_chunks(int N, int Hi, int Wi, int stride, int pad) {
 }
 
 // Data gradient with the BatchNorm-backward passes on both sides folded in:
-//   operand   dY = A*g + nK2*yraw + C2, bcoef [4][Co] = {A, nK2, C2, mean}
+//   operand   dY = A*g + nK2*yraw + C2, bcoef [4][Co] = {A, nK2, C2, mean}; yraw == bcoef == NULL: g_in IS dY (a materialised
+//             d_raw: units that run on the plain operand path but keep the epilogue -- encoders mid_sep / wide blocks)
 //   epilogue  (ep_raw != NULL) dx is the gradient of relu?(bn(ep_raw)) of the layer below: it is masked with ep_mask (sign
 //             bytes [pixel][Ci/4]) or, when ep_mask == NULL and ep_relu, with the decision recomputed from ep_raw and
 //             ep_fcoef [5][Ci] = {mean, rstd, scale, shift, shift2}; the masked gradient is stored and (sum g, sum g*xhat) per
@@ -2550,9 +2551,11 @@ int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g_in, const float* yraw, const fl
                                   int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad,
                                   int flags, const float* ep_raw, const unsigned char* ep_mask, const float* ep_fcoef,
                                   int ep_relu, float* ep_part, size_t ep_part_bytes, hipStream_t st) {
-  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || !g_in || !yraw ||
-      !bcoef || (Co % 16) || (Ci % 4))
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Ci <= 0 || Ho <= 0 || Wo <= 0 || Co <= 0 || stride <= 0 || pad < 0 || !g_in ||
+      (!yraw != !bcoef) || (Co % 16) || (Ci % 4))
     return EDRL_EINVAL;
+  const bool plain_in = !yraw;
+  if (plain_in && !ep_raw) return EDRL_EINVAL;      // (no transform on either side: that is edrl_conv2d_nhwc_dgrad_f32)
   if ((long)N * Hi * Wi > 0x7fffffffL) return EDRL_EINVAL;
   if (ep_raw && (!ep_fcoef || !ep_part)) return EDRL_EINVAL;
   if (ep_raw && ep_part_bytes < (size_t)edrl_conv_dgrad_bn_chunks(N, Hi, Wi, stride, pad) * 2 * Ci * sizeof(float))
@@ -2593,7 +2596,9 @@ int edrl_conv2d_nhwc_dgrad_bn_f32(const float* g_in, const float* yraw, const fl
       F.ep_chunk0 = chunk0;
       // EPI 2 = the instantiation whose lean epilogue is specialised for (sign bytes, accumulate); EPI 1 for (recomputed
       // ReLU decision, no accumulate); both carry the general epilogue for every other combination
-      const int rc = !ep_raw ? dispatch_gather_fused<true, 2, 0>(g_in, wt, dx, g, F, st)
+      const int rc = plain_in ? (ep_mask ? dispatch_gather_fused<true, 0, 2>(g_in, wt, dx, g, F, st)
+                                         : dispatch_gather_fused<true, 0, 1>(g_in, wt, dx, g, F, st))
+                     : !ep_raw ? dispatch_gather_fused<true, 2, 0>(g_in, wt, dx, g, F, st)
                      : (ep_mask && (flags & GF_ACCUM)) ? dispatch_gather_fused<true, 2, 2>(g_in, wt, dx, g, F, st)
                                                        : dispatch_gather_fused<true, 2, 1>(g_in, wt, dx, g, F, st);
       if (rc) return rc;

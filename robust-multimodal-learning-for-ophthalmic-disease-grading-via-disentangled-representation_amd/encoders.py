@@ -179,6 +179,12 @@ def _dbg_draw(g, raw, bc):
 # Kernel sets: the trunk's forward/backward schedule (_TrunkFn) is written once; what differs between the fp32 trunk (C1/C3)
 # and the bf16 trunk (C2/C4: bf16 activations / gradients and bf16 MFMA convs, fp32 BatchNorm statistics, fp32 weights and
 # weight gradients, fp32 stem) is which launchers it calls.
+def _f32_split_build():
+    """Does the loaded library form fp32 products as bf16x3 splits (include/edrl_hip.h edrl_f32_contraction_split)?  Decides the
+    default block policy of the fp32 trunk only (the fp32-MFMA build is best all-fused)."""
+    return bool(L.lib().fn["edrl_f32_contraction_split"]())
+
+
 class _K32:
     act_dtype = torch.float32
     conv_bn_fwd = staticmethod(lambda *a, **k: _conv_bn_fwd(*a, **k))
@@ -193,9 +199,21 @@ class _K32:
     wgrad_bn = staticmethod(lambda *a: ops.conv2d_wgrad_bn(*a))
     dgrad_bn = staticmethod(lambda *a, **k: ops.conv2d_dgrad_bn(*a, **k))
     apply_res_name, reduce_name, elt = "edrl_bn_apply_res_f32", "edrl_bn_bwd_reduce_f32", 4.0
-    fuse_max_planes = 1 << 30        # every residual stage takes the fused-BatchNorm path
-    mid_sep = False                  # (bf16 only) the 3x3 layer of a fused bottleneck block on the plain kernels
-    wide_sep = False                 # (bf16 only) see _KBF16
+    # Since the fp32 contractions run as bf16x3 splits on the bf16 MFMA (csrc/conv_gemm.hip EDRL_F32_SPLIT) the matrix pipe is 2.7x
+    # faster per fp32 product and the operand transforms of the fused kernels are no longer hidden behind it: per layer at 1056
+    # images (profiles/r05_fused_layers_split_1056img.txt) the fused form still wins on every 1x1 layer of stages 1-3 (two K-wide
+    # tensors never stored) but loses on every 3x3 layer (transforms re-applied per tap: l3 3x3 4.11 -> 4.68 ms per unit) and on
+    # stage 4.  So the fp32 trunk takes the bf16 trunk's policy (see _KBF16): mid_sep -- the 3x3 layer of a fused bottleneck block on
+    # the plain kernels -- and above fuse_max_planes "wide" blocks (materialised activations and d_raw, BatchNorm-backward statistics
+    # still from the data gradients' epilogues).  Measured on the C1 step, one box, in order (scripts/gpu_f32_policy_sweep.sh):
+    # all fused 69.8 images/s (138.6 GiB) -> mid_sep 73.1 (148.8 GiB) -> + wide stage 4 73.2-73.4 (150.4) -> + wide stage 3 73.3
+    # (154.5) -> + wide stage 2 72.6: mid_sep is the gain, wide blocks are neutral, so the default keeps every block fused
+    # (EDRL_F32_FUSE_MAXPLANES=256 / 128: wide blocks from stage 4 / 3 up).  EDRL_F32_MID_SEP=0: the all-fused trunk of rounds 2-4
+    # (what the fp32-MFMA build is best with).
+    fuse_max_planes = int(os.environ.get("EDRL_F32_FUSE_MAXPLANES", str(1 << 30)))
+    mid_sep = os.environ.get("EDRL_F32_MID_SEP", "1" if _f32_split_build() else "0") != "0"
+    wide_sep = os.environ.get("EDRL_F32_WIDE_SEP", "1") != "0"
+    mx, draw_name = 0, "edrl_bn_draw_f32"       # storage flag of the _mx entry points; the standalone d_raw pass
     conv3_bwd_ok = staticmethod(lambda *a: False)       # (bf16 only) one-pass backward of the expanding 1x1 layers
     conv3_bwd = None
     grad_in = staticmethod(lambda dout: dout.contiguous())
@@ -328,6 +346,7 @@ class _KBF16:
     # mask) and the separate dres tensor of the block's last BatchNorm; the block output comes from bn_apply_res as in a fused block,
     # so the gradient hand-over between blocks stays ("masked", g, partials).  EDRL_BF16_WIDE_SEP=0: the separate passes of round 3.
     wide_sep = os.environ.get("EDRL_BF16_WIDE_SEP", "1") != "0"
+    mx, draw_name = 1, "edrl_bn_draw_bf16"
     conv3_bwd_ok = staticmethod(lambda *a: ops.conv1x1_k64_bwd_ok_bf16(*a))
     conv3_bwd = staticmethod(lambda *a: ops.conv1x1_k64_bwd_bf16(*a))
     grad_in = staticmethod(lambda dout: ops.to_bf16(dout.contiguous()))
@@ -488,8 +507,8 @@ class _TrunkFn(torch.autograd.Function):
             M = raw.numel() // C
             act = torch.empty_like(raw)
             kb = torch.empty((M, C // 4), device=raw.device, dtype=torch.uint8)
-            ops.call_timed_bytes("bn_apply", M * C * 4.25, "edrl_bn_apply_mx", P(raw), 1, P(fc[0]), P(fc[2]), P(fc[3]), None, P(act), 1,
-                                 P(kb), M, C, 1)
+            ops.call_timed_bytes("bn_apply", M * C * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(raw), K.mx, P(fc[0]), P(fc[2]), P(fc[3]), None,
+                                 P(act), K.mx, P(kb), M, C, 1)
             return act, kb
 
         p0, saved["stem"] = K.stem_fwd(T, x, p, bnd, cap, cb)
@@ -524,10 +543,12 @@ class _TrunkFn(torch.autograd.Function):
                         M1 = c1.numel() // C1
                         a1 = torch.empty_like(c1)
                         k1 = torch.empty((M1, C1 // 4), device=c1.device, dtype=torch.uint8)
-                        ops.call_timed_bytes("bn_apply", M1 * C1 * 4.25, "edrl_bn_apply_mx", P(c1), 1, P(f1[0]), P(f1[2]), P(f1[3]), None,
-                                             P(a1), 1, P(k1), M1, C1, 1)
+                        ops.call_timed_bytes("bn_apply", M1 * C1 * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(c1), K.mx, P(f1[0]), P(f1[2]),
+                                             P(f1[3]), None, P(a1), K.mx, P(k1), M1, C1, 1)
                         c2, f2 = cf(pre + ".conv2", pre + ".bn2", a1, None, s, 1)
-                        rec.update(a1=a1, k1=k1, mid_sep=True)
+                        # recompute mode: the activated copy and its sign bytes are rebuilt in backward by the same pass
+                        keep_a1 = not (T.recompute_out and cap is None)
+                        rec.update(a1=a1 if keep_a1 else None, k1=k1 if keep_a1 else None, mid_sep=True)
                         if cap is not None:
                             cap[pre + ".conv1"].update(out=a1, mask=k1)
                     else:
@@ -785,7 +806,7 @@ class _TrunkFn(torch.autograd.Function):
                     def draw(g_, raw_, bc_):
                         Cc = raw_.shape[-1]
                         d_ = torch.empty_like(raw_)
-                        ops.call_timed_bytes("bn_draw", raw_.numel() * 6.0, "edrl_bn_draw_bf16", P(g_), P(raw_), P(bc_), P(d_),
+                        ops.call_timed_bytes("bn_draw", raw_.numel() * 3 * K.elt, K.draw_name, P(g_), P(raw_), P(bc_), P(d_),
                                              raw_.numel() // Cc, Cc)
                         return d_
 
@@ -840,9 +861,16 @@ class _TrunkFn(torch.autograd.Function):
                     b2 = fin_bwd(pre + ".bn2", part, chunks, 2, c2, f2)
                     planes1 = 2
                     if rec.get("mid_sep"):
+                        if rec["a1"] is None:      # recompute mode: bit-identical to the forward's pass
+                            C1 = c1.shape[-1]
+                            M1 = c1.numel() // C1
+                            rec["a1"] = torch.empty_like(c1)
+                            rec["k1"] = torch.empty((M1, C1 // 4), device=c1.device, dtype=torch.uint8)
+                            ops.call_timed_bytes("bn_apply", M1 * C1 * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(c1), K.mx, P(f1[0]), P(f1[2]),
+                                                 P(f1[3]), None, P(rec["a1"]), K.mx, P(rec["k1"]), M1, C1, 1)
                         C2c = c2.shape[-1]
                         d2 = torch.empty_like(c2)
-                        ops.call_timed_bytes("bn_draw", c2.numel() * 6.0, "edrl_bn_draw_bf16", P(g2), P(c2), P(b2), P(d2), c2.numel() // C2c, C2c)
+                        ops.call_timed_bytes("bn_draw", c2.numel() * 3 * K.elt, K.draw_name, P(g2), P(c2), P(b2), P(d2), c2.numel() // C2c, C2c)
                         w2 = p[pre + ".conv2.weight"]
                         grads[pre + ".conv2.weight"] = K.conv_wgrad(d2, rec["a1"], tuple(w2.shape), s, 1)
                         # plain operand (d2 is materialised), epilogue as in the fused chain: masked with bn1's sign bytes,
@@ -852,7 +880,8 @@ class _TrunkFn(torch.autograd.Function):
                         if cap is not None:
                             cap["bwd:" + pre + ".bn2"] = dict(dout=g2.clone(), dgamma=grads[pre + ".bn2.weight"],
                                                             dbeta=grads[pre + ".bn2.bias"], d_raw=d2, dres=None, masked=True)
-                            cap[pre + ".conv2"].update(d_raw=d2, dW=grads[pre + ".conv2.weight"], dx_before=None, dx_after=g1.clone())
+                            cap[pre + ".conv2"].update(d_raw=d2, dW=grads[pre + ".conv2.weight"], dx_before=None, dx_after=g1.clone(),
+                                                       dx_keep=_mask_to_bool(rec["k1"], c1.shape))
                         del d2
                     else:
                         fwgrad(pre + ".conv2", g2, c2, b2, c1, f1, s, 1)

@@ -381,7 +381,7 @@ def conv2d_dgrad_bn(g, yraw, bcoef, wt, x_shape, stride=1, pad=0, out=None, accu
     _launch_timed("conv_gather", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_dgrad_bn_f32", P(g), P(yraw), P(bcoef),
                   P(wt), P(out), N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, FLAG_ACCUM if accumulate else 0, P(ep_raw),
                   P(ep_mask), P(ep_fcoef), 1 if ep_relu else 0, P(part), nbytes, kernels=kernels,
-                  nbytes=4.0 * (2 * g.numel() + wt.numel() + out.numel() * (2 if accumulate else 1) +
+                  nbytes=4.0 * ((2 if yraw is not None else 1) * g.numel() + wt.numel() + out.numel() * (2 if accumulate else 1) +
                                 (out.numel() if ep is not None else 0)))
     return out if ep is None else (out, part, chunks)
 
