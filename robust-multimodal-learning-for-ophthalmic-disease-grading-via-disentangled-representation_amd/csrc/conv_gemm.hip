@@ -61,23 +61,38 @@ typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sp_bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int sp_u32x2 __attribute__((ext_vector_type(2)));
 typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
-// exact three-way split of four fp32 values into bf16 planes (round to nearest even at every level; remainders are exact)
+// exact three-way split of four fp32 values into bf16 planes (round to nearest even at every level; remainders are exact).
+// Per pair of elements and level: one v_cvt_pk_bf16_f32 and two v_dot2c_f32_bf16 -- the remainder a - hi comes straight from the
+// PACKED pair, r = (hi0, hi1) . (-1, 0) + a0 (a dot product with a constant selects and widens the half in one instruction; the
+// sum -hi + a is exact in fp32, so any rounding inside the dot product is a no-op): 14 vector instructions per 4 elements
+// instead of 22 with an unpack + subtract per element.
+typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void edrl_split3(sp_f32x4 v, sp_u32x2& p0, sp_u32x2& p1, sp_u32x2& p2) {
-  sp_bf16x4 h, m, l;
+  // The selectors (-1, 0) / (0, -1) must reach the instruction as register operands: written as constants the compiler folds
+  // (-1, 0) into the inline operand -1.0, which the hardware reads as the packed pair (0, -1) (scripts/microbench/
+  // dot2_bf16_probe.hip: a0 - h1 comes back) -- so they are materialised through an opaque move.
+  unsigned s0u = 0x0000BF80u, s1u = 0xBF800000u;
+  asm volatile("" : "+s"(s0u), "+s"(s1u));
+  const sp_bf16x2 sel0 = __builtin_bit_cast(sp_bf16x2, s0u), sel1 = __builtin_bit_cast(sp_bf16x2, s1u);
+  sp_bf16x2 h[2], m[2], l[2];
   sp_f32x4 r, r2;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+  for (int q = 0; q < 2; ++q) {
+    h[q][0] = (__bf16)v[2 * q]; h[q][1] = (__bf16)v[2 * q + 1];
+    r[2 * q] = __builtin_amdgcn_fdot2_f32_bf16(h[q], sel0, v[2 * q], false);
+    r[2 * q + 1] = __builtin_amdgcn_fdot2_f32_bf16(h[q], sel1, v[2 * q + 1], false);
+  }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = v[e] - (float)h[e];
+  for (int q = 0; q < 2; ++q) {
+    m[q][0] = (__bf16)r[2 * q]; m[q][1] = (__bf16)r[2 * q + 1];
+    r2[2 * q] = __builtin_amdgcn_fdot2_f32_bf16(m[q], sel0, r[2 * q], false);
+    r2[2 * q + 1] = __builtin_amdgcn_fdot2_f32_bf16(m[q], sel1, r[2 * q + 1], false);
+  }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) m[e] = (__bf16)r[e];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) r2[e] = r[e] - (float)m[e];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) l[e] = (__bf16)r2[e];
-  p0 = __builtin_bit_cast(sp_u32x2, h);
-  p1 = __builtin_bit_cast(sp_u32x2, m);
-  p2 = __builtin_bit_cast(sp_u32x2, l);
+  for (int q = 0; q < 2; ++q) { l[q][0] = (__bf16)r2[2 * q]; l[q][1] = (__bf16)r2[2 * q + 1]; }
+  p0[0] = __builtin_bit_cast(unsigned, h[0]); p0[1] = __builtin_bit_cast(unsigned, h[1]);
+  p1[0] = __builtin_bit_cast(unsigned, m[0]); p1[1] = __builtin_bit_cast(unsigned, m[1]);
+  p2[0] = __builtin_bit_cast(unsigned, l[0]); p2[1] = __builtin_bit_cast(unsigned, l[1]);
 }
 // Weight-gradient image of the split path: per plane [16 pixels][W channels] bf16, unpadded; the 64-byte granule index of a row
 // is XORed with a function of the pixel row so that the four rows of a transposing-read block (ds_read_b64_tr_b16: 4 pixels x 16
