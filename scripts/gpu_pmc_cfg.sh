@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmc_${CFG}_$tag
-  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${CFG}_$tag -- python3 $R/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs > $R/gpurun_out/pmc_${CFG}_$tag.log 2>&1; rc=$?; echo "pmc $tag exit=$rc" >> $R/gpurun_out/pmc_${CFG}_$tag.log
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${CFG}_$tag -- python3 $R/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --in-order --no-recompute-leg --no-anchor-leg --no-bf16-legs --no-f32-mfma-leg > $R/gpurun_out/pmc_${CFG}_$tag.log 2>&1; rc=$?; echo "pmc $tag exit=$rc" >> $R/gpurun_out/pmc_${CFG}_$tag.log
   tail -1 $R/gpurun_out/pmc_${CFG}_$tag.log
   [ $rc -eq 0 ] || exit $rc
 done
