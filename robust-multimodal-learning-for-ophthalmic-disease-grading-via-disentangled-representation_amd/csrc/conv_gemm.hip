@@ -116,9 +116,12 @@ __device__ __forceinline__ sp_bf16x8 edrl_wsplit_frag(const char* plane, int pix
   u.s.l = lo; u.s.h = hi;
   return u.v;
 }
-constexpr int edrl_wgrad_occ(int bkt, bool fastld, int occ) {
+// (the variant with both operand transforms needs 190 registers: at 3 per CU it spills and runs 14 % slower than at 2,
+// profiles/r05_f32_split_occ_ab.txt)
+constexpr int edrl_wgrad_occ(int bkt, bool fastld, int occ, int xt) {
   if (!(EDRL_F32_SPLIT != 0 && bkt == 16 && fastld)) return occ;
-  return occ > EDRL_F32_SPLIT_OCC ? EDRL_F32_SPLIT_OCC : occ;
+  const int cap = xt != 0 ? 2 : EDRL_F32_SPLIT_OCC;
+  return occ > cap ? cap : occ;
 }
 
 template <int BM, int BN, bool DGRAD, bool VEC>
@@ -1519,7 +1522,7 @@ struct WgradFuse {
 // tap 0 and its wrap at a sample boundary), the depth tap of a column is a per-thread constant like its (kh, kw).
 template <int BM, int BN, bool VEC, int BKT, int OCC, bool FASTLD = false, int DYT = 0, int XT = 0, bool MASKX = true,
           bool DY16 = false, bool VOL = false>
-__global__ __launch_bounds__(256, edrl_wgrad_occ(BKT, FASTLD, OCC)) void conv_wgrad_f32_kernel(
+__global__ __launch_bounds__(256, edrl_wgrad_occ(BKT, FASTLD, OCC, XT)) void conv_wgrad_f32_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, WgradGeom g, WgradFuse F) {
   static_assert((DYT == 0 && XT == 0) || FASTLD, "operand transforms ride on the buffer-descriptor path");
   static_assert(!VOL || (FASTLD && DYT == 0 && XT == 0 && !DY16), "depth taps: plain buffer-load path only");
