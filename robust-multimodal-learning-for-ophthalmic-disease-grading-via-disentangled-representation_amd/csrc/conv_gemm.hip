@@ -48,13 +48,19 @@
 #ifndef EDRL_F32_SPLIT
 #define EDRL_F32_SPLIT 1      // 0: fp32 MFMA (libedrl_hip_f32mfma.so is this file compiled with -DEDRL_F32_SPLIT=0)
 #endif
+#ifndef EDRL_F32_SPLIT_OCC_EPI2
+#define EDRL_F32_SPLIT_OCC_EPI2 3   // ... of the plain-operand data gradient with the sign-byte epilogue
+#endif
+#ifndef EDRL_F32_SPLIT_OCC_ATR2
+#define EDRL_F32_SPLIT_OCC_ATR2 2   // ... of the data-gradient variants that form d_raw in the operand load (200-245 registers)
+#endif
 #ifndef EDRL_F32_SPLIT_OCC
 #define EDRL_F32_SPLIT_OCC 3    // workgroups per CU of the split kernels (48 KiB of LDS each at 128 x 128)
 #endif
 // workgroups per CU of a gather-kernel variant: the split K loop keeps two register sets of operand loads in flight
-constexpr int edrl_gather_occ(int bkt, bool fast, bool buf, int atr, int occ) {
+constexpr int edrl_gather_occ(int bkt, bool fast, bool buf, int atr, int occ, int epi = 0) {
   if (!(EDRL_F32_SPLIT != 0 && bkt == 16 && fast && buf)) return occ;
-  const int cap = atr == 2 ? 2 : EDRL_F32_SPLIT_OCC;
+  const int cap = atr == 2 ? EDRL_F32_SPLIT_OCC_ATR2 : (epi == 2 ? EDRL_F32_SPLIT_OCC_EPI2 : EDRL_F32_SPLIT_OCC);
   return occ > cap ? cap : occ;
 }
 typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
@@ -387,7 +393,7 @@ __device__ __forceinline__ u32x2 edrl_pack_bf16x4(f32x4 v) {
 // geometry over a depth-reversed, class-compacted weight matrix (no kernel code of its own).
 template <int BM, int BN, bool DGRAD, int BKT, int OCC, bool FAST, bool BUF = false, int ATR = 0, int EPI = 0, bool MASK = true,
           bool OUT16 = false, bool VOL = false>
-__global__ __launch_bounds__(256, edrl_gather_occ(BKT, FAST, BUF, ATR, OCC))
+__global__ __launch_bounds__(256, edrl_gather_occ(BKT, FAST, BUF, ATR, OCC, EPI))
 void conv_gather_f32_v2_kernel(
     const float* __restrict__ src, const float* __restrict__ wm, float* __restrict__ dst,
     const float* __restrict__ bias, const float* __restrict__ mul, GatherGeom g, int tiles_n, GatherSplit S, GatherFuse F) {
