@@ -30,6 +30,11 @@ sys.path.insert(0, ROOT)
 # dmabuf IPC is the only mode this host driver supports (RCCL / cross-process device memory); it has to be in the environment
 # before the HSA runtime starts, i.e. before the first torch.cuda call, not only before init_process_group
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# hardware queues per process (ROCclr default 4): a step uses the compute stream, the second view's stream, GradSync's
+# communication stream and RCCL's own -- with 4 queues the two compute streams end up sharing one and the two-view overlap is lost
+# (measured, C1 with a 1-rank RCCL process group: 74.2 images/s, 77.0 with 8 queues = the rate without a process group).  Read
+# when the HIP runtime starts, so it must be set before the first torch.cuda call; the package sets the same default on import.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 CONFIGS = {
     # name: (per-GPU batch, encoder depth, H=W, slices, encoder dtype, description)
@@ -214,6 +219,16 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         edrl_amd.dist.init_process_group(backend, device=dev)      # fail-fast: a failed / hung collective aborts the rank
+    # EDRL_BENCH_FORCE_SYNC=1 (diagnostic, N = 1 only): run the step through the N > 1 machinery -- a 1-rank process group on the
+    # real backend and GradSync(force_collective=True): buckets, the trunks' per-stage release, the communication stream and its
+    # events, finish() -- to see what that machinery costs next to the plain step on the same box (RCCL short-cuts the 1-rank
+    # all-reduce itself: no reduction kernel, no xGMI byte).
+    force_sync = world == 1 and os.environ.get("EDRL_BENCH_FORCE_SYNC") in ("1", "pgonly")
+    pg_only = os.environ.get("EDRL_BENCH_FORCE_SYNC") == "pgonly"      # (lab: the process group alone, no GradSync)
+    if force_sync:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        edrl_amd.dist.init_process_group(backend, device=dev)
 
     if a.config is None:
         a.config = "C1" if a.gpus == 1 else "C3"
@@ -237,7 +252,7 @@ def main():
         opt = (torch.optim.Adam if a.torch_adam else edrl_amd.FusedAdam)(model.parameters(), lr=1e-4, weight_decay=1e-6)
         data, y = edrl_amd.synthetic_batch(B, HW, HW, S, device=dev, seed=1234, rank=rank, drop_oct_high=(cfg == "C4"))
         run.clear()
-        run.update(model=model, opt=opt, data=data, y=y, sync=edrl_amd.GradSync(model) if world > 1 else None)
+        run.update(model=model, opt=opt, data=data, y=y, sync=edrl_amd.GradSync(model, force_collective=force_sync) if (world > 1 or (force_sync and not pg_only)) else None)
         return dict(cfg=cfg, B=B, depth=depth, HW=HW, S=S, enc_dtype=enc_dtype, desc=desc, recompute=rec)
 
     def drop():
@@ -498,7 +513,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(depth, HW, S, dev)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_sync:
         dist.destroy_process_group()
 
 

@@ -7,6 +7,15 @@ Drop-in surface:
 Compute lives in libedrl_hip.so (hand-written HIP, C-ABI in include/edrl_hip.h); importing this
 package never builds or falls back: a missing library raises on first use.
 """
+import os as _os
+
+# Hardware queues per process (ROCclr default 4).  A data-parallel step runs on the compute stream, the second view's stream
+# (train.train_step), GradSync's communication stream and RCCL's internal one; with 4 queues the two compute streams share a queue
+# as soon as a process group exists and the two-view overlap is lost (C1, 1-rank RCCL group: 74.2 -> 77.0 images/s with 8).  The
+# runtime reads the variable when HIP starts: effective if this import precedes the process's first GPU call (bench.py and the
+# launch line of INTEGRATION.md set it in the environment as well); dist.init_process_group warns when it came too late.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from . import _lib, ops
 from . import custom_ops          # registers torch.ops.edrl.* (torch.library schemas over the same C-ABI launchers)
 from .mmd import MK_MMD, compute_js_divergence, compute_kl_divergence

@@ -32,6 +32,14 @@ def init_process_group(backend="nccl", device=None, timeout_s=180):
     process (after `timeout_s`) instead of leaving the other ranks blocked in backward."""
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")      # tear the process down on a collective error
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (the only mode this host driver supports)
+    try:                                                                # (see the package __init__: the two compute streams need queues of their own)
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+            import warnings
+            warnings.warn("GPU_MAX_HW_QUEUES < 8: with a process group active the two-view stream overlap of train_step shares a "
+                          "hardware queue with the communication streams (-4 % step throughput at C1); export GPU_MAX_HW_QUEUES=8 "
+                          "before the process touches the GPU")
+    except ValueError:
+        pass
     kw = dict(timeout=datetime.timedelta(seconds=timeout_s))
     if backend == "nccl" and device is not None:
         kw["device_id"] = device
@@ -149,6 +157,9 @@ class GradSync:
         if not b["seen"][si]:
             b["seen"][si] = True
             b["ready"] += 1
+        if self.comm_stream is not None:                     # streams whose work this bucket's gradients come from
+            cur = torch.cuda.current_stream()
+            b.setdefault("streams", {})[cur.cuda_stream] = cur
         if b["ready"] >= len(b["params"]):
             self._launch(b)
 
@@ -207,9 +218,15 @@ class GradSync:
         inv = 1.0 / self.world
         self.collectives_issued += 1
         if self.comm_stream is not None:
-            ev = torch.cuda.current_stream().record_event()
+            # The exchange waits for every stream that produced one of the bucket's gradients (the two views run on two streams:
+            # normally the trunks' last pass and the head are all on one of them and has already waited for the other's stage
+            # events, but nothing forces a bucket's parameters onto one stream).
+            cur = torch.cuda.current_stream()
+            evs = [cur.record_event()] + [st.record_event() for sid, st in b.get("streams", {}).items() if sid != cur.cuda_stream]
+            b["streams"] = {}
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
+                for ev in evs:
+                    self.comm_stream.wait_event(ev)
                 b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 b["handle"].wait()                           # orders the scale after the collective ON the comm stream
                 b["handle"] = None

@@ -9,6 +9,6 @@ for r in 1 2; do
   for e in "$@"; do
     i=$((i+1))
     ( [ "$e" = "-" ] || export $e; timeout -k 10 300 python3 bench.py $ARGS > gpurun_out/${TAG}_${i}_$r.json 2> gpurun_out/${TAG}_${i}_$r.err ) || { echo "FAILED $e"; tail -3 gpurun_out/${TAG}_${i}_$r.err; exit 1; }
-    python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_${i}_$r.json')); print('round $r  [$e]', d['value'], d['ms_per_step'], d['peak_mem_GiB'])"
+    python3 -c "import json; d=json.loads([l for l in open('gpurun_out/${TAG}_${i}_$r.json') if l.startswith('{')][-1]); print('round $r  [$e]', d['value'], d['ms_per_step'], d['peak_mem_GiB'])"
   done
 done
