@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads, exports every symbol include/edrl_hip.h declares, rejects bad arguments
 without touching a GPU, and the Python host layer mirrors the reference's module surface."""
 import ctypes
+import os
 import types
 
 import pytest
@@ -202,3 +203,18 @@ def test_shipped_library_holds_no_diagnostic_kernels_and_switches_reload(edrl):
     assert fn["edrl_conv3d_wgrad_ok_f32"](2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3) == 1
     assert fn["edrl_conv3d_wgrad_ok_f32"](2, 4, 8, 8, 6, 4, 8, 8, 16, 3, 3, 3) == 0           # Ci % 4
     assert fn["edrl_conv3d_ndhwc_wgrad_f32"](None, None, None, None, 0, 2, 4, 8, 8, 16, 4, 8, 8, 16, 3, 3, 3, 1, 1, 1, 1, 0, None) == -22
+
+
+def test_package_import_sets_hardware_queue_default():
+    """with the runtime's default of 4 hardware queues per process the second view's stream shares a queue once
+    a process group exists; the package asks for 8 unless the environment already says otherwise."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", "import os, edrl_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert r.stdout.strip().splitlines()[-1] == "8"
+    r = subprocess.run([sys.executable, "-c", "import os, edrl_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"], cwd=root,
+                       env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip().splitlines()[-1] == "4"
