@@ -2382,6 +2382,8 @@ static int wgrad_impl(const float* dy, const float* x, float* dw, float* workspa
     if (dyt && xt && maskx) rc = wgrad_fused_launch<2, 1, true>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
     else if (dyt && xt) rc = wgrad_fused_launch<2, 1, false>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
     else if (dyt) rc = wgrad_fused_launch<2, 0, true>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
+    else if (xt && maskx) rc = wgrad_fused_launch<0, 1, true>(dy, x, workspace, g, bm, bn, splits, *fuse, st);     // (dY materialised)
+    else if (xt) rc = wgrad_fused_launch<0, 1, false>(dy, x, workspace, g, bm, bn, splits, *fuse, st);
     else return EDRL_EINVAL;
   } else if (fast) {
     if (bm == 64 && bn == 64) rc = launch_wgrad<64, 64, true, true>(dy, x, workspace, g, splits, st);
@@ -2513,12 +2515,14 @@ int edrl_conv2d_nhwc_wgrad_f32_dybf16(const void* dy_bf16, const float* x, float
 //                                          output, bcoef [4][Co] = {A, nK2, C2, mean} (edrl_bn_bwd_finalize_partials_f32)
 //   X  = relu(x*scale + shift2)            when x_fcoef [5][Ci] = {mean, rstd, scale, shift, shift2} of the PREVIOUS layer's BatchNorm
 //                                          is given (x is then that layer's raw conv output); x as is when x_fcoef == NULL
+//   yraw == bcoef == NULL (with x_fcoef): g IS dY, a materialised d_raw (encoders._K32 draw_sep units)
 // Needs the buffer-load fast path (edrl_conv2d_fused_ok_f32): -22 otherwise.
 int edrl_conv2d_nhwc_wgrad_bn_f32(const float* g, const float* yraw, const float* bcoef, const float* x,
                                   const float* x_fcoef, float* dw, float* workspace, size_t workspace_bytes, int N, int Hi,
                                   int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int accumulate,
                                   hipStream_t st) {
-  if (!g || !yraw || !bcoef || !x) return EDRL_EINVAL;
+  if (!g || (!yraw != !bcoef) || !x) return EDRL_EINVAL;
+  if (!yraw && !x_fcoef) return EDRL_EINVAL;        // (no transform on either side: that is edrl_conv2d_nhwc_wgrad_f32)
   WgradFuse F;
   F.dy2 = yraw; F.bcoef = bcoef; F.xcoef = x_fcoef;
   return wgrad_impl(g, x, dw, workspace, workspace_bytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, Co, Ci, accumulate,

@@ -214,6 +214,13 @@ class _K32:
     mid_sep = os.environ.get("EDRL_F32_MID_SEP", "1" if _f32_split_build() else "0") != "0"
     wide_sep = os.environ.get("EDRL_F32_WIDE_SEP", "1") != "0"
     mx, draw_name = 0, "edrl_bn_draw_f32"       # storage flag of the _mx entry points; the standalone d_raw pass
+    # draw_sep (split build): in blocks of at least this many planes the BACKWARD of the 1x1 units takes a materialised d_raw too
+    # (one edrl_bn_draw_f32 pass per unit, then the plain-operand weight / data gradient, epilogues unchanged).  The kernels that
+    # form d_raw in their operand loads need 200-245 registers: 2 workgroups per CU, matrix pipe 49 % busy against 70 % of the
+    # plain ones at 3 (profiles/r05_pmc_f32_split_fused_1x1.txt).  Measured on the C1 step, one box (scripts/gpu_env_sweep.sh):
+    # off 78.1 images/s, from 512 planes (stage 4) 78.5, from 256 78.0, from 128 77.0 -- the extra pass over the d_raw tensors eats
+    # the gain everywhere but on the 7 x 7 maps.  The forward stays fused.  EDRL_F32_DRAW_SEP_MINPLANES=1073741824: off.
+    draw_sep_min_planes = int(os.environ.get("EDRL_F32_DRAW_SEP_MINPLANES", "512" if _f32_split_build() else str(1 << 30)))
     conv3_bwd_ok = staticmethod(lambda *a: False)       # (bf16 only) one-pass backward of the expanding 1x1 layers
     conv3_bwd = None
     grad_in = staticmethod(lambda dout: dout.contiguous())
@@ -347,6 +354,7 @@ class _KBF16:
     # so the gradient hand-over between blocks stays ("masked", g, partials).  EDRL_BF16_WIDE_SEP=0: the separate passes of round 3.
     wide_sep = os.environ.get("EDRL_BF16_WIDE_SEP", "1") != "0"
     mx, draw_name = 1, "edrl_bn_draw_bf16"
+    draw_sep_min_planes = 1 << 30
     conv3_bwd_ok = staticmethod(lambda *a: ops.conv1x1_k64_bwd_ok_bf16(*a))
     conv3_bwd = staticmethod(lambda *a: ops.conv1x1_k64_bwd_bf16(*a))
     grad_in = staticmethod(lambda dout: ops.to_bf16(dout.contiguous()))
@@ -722,9 +730,19 @@ class _TrunkFn(torch.autograd.Function):
             grads[bn_name + ".bias"] = db
             return bc
 
-        def fwgrad(name, g, raw, bc, xin, x_fc, stride, pad):
+        def fwgrad(name, g, raw, bc, xin, x_fc, stride, pad, d=None):
             w = p[name + ".weight"]
+            if d is not None:       # d = the unit's materialised d_raw (draw_sep)
+                grads[name + ".weight"] = (K.conv_wgrad(d, xin, tuple(w.shape), stride, pad) if x_fc is None else
+                                           K.wgrad_bn(d, None, None, xin, x_fc, tuple(w.shape), stride, pad))
+                return
             grads[name + ".weight"] = K.wgrad_bn(g, raw, bc, xin, x_fc, tuple(w.shape), stride, pad)
+
+        def draw_of(g, raw, bc):
+            C_ = raw.shape[-1]
+            d_ = torch.empty_like(raw)
+            ops.call_timed_bytes("bn_draw", raw.numel() * 3 * K.elt, K.draw_name, P(g), P(raw), P(bc), P(d_), raw.numel() // C_, C_)
+            return d_
 
         def fcap(conv_name, bn_name, g, raw, bc, dres=None):
             if cap is not None:
@@ -733,9 +751,14 @@ class _TrunkFn(torch.autograd.Function):
                                              d_raw=dr, dres=dres, masked=True)
                 cap[conv_name].update(d_raw=dr, dW=grads[conv_name + ".weight"])
 
-        def fdgrad(name, g, raw, bc, x_shape, stride, pad, out=None, accumulate=False, ep=None, ep_keep=None):
+        def fdgrad(name, g, raw, bc, x_shape, stride, pad, out=None, accumulate=False, ep=None, ep_keep=None, d=None):
             before = out.clone() if (cap is not None and accumulate) else None
-            r = K.dgrad_bn(g, raw, bc, wt_of(name), tuple(x_shape), stride, pad, out=out, accumulate=accumulate, ep=ep)
+            if d is not None and ep is None:
+                r = K.conv_dgrad(d, wt_of(name), tuple(x_shape), stride, pad, out=out, accumulate=accumulate)
+            elif d is not None:
+                r = K.dgrad_bn(d, None, None, wt_of(name), tuple(x_shape), stride, pad, out=out, accumulate=accumulate, ep=ep)
+            else:
+                r = K.dgrad_bn(g, raw, bc, wt_of(name), tuple(x_shape), stride, pad, out=out, accumulate=accumulate, ep=ep)
             if cap is not None:
                 cap[name].update(dx_before=before, dx_after=(r if ep is None else r[0]).clone(),
                                  dx_keep=ep_keep() if (ep is not None and ep_keep is not None) else None)
@@ -792,6 +815,7 @@ class _TrunkFn(torch.autograd.Function):
             out_cache.pop(bi, None)
             if rec.get("fused"):
                 bott = T.kind == "bottleneck"
+                dsep = bott and not rec.get("wide") and rec["c1"].shape[-1] >= K.draw_sep_min_planes
                 last, last_bn = (pre + ".conv3", pre + ".bn3") if bott else (pre + ".conv2", pre + ".bn2")
                 cl, fl = (rec["c3"], rec["f3"]) if bott else (rec["c2"], rec["f2"])
                 if grad_in[0] == "plain":
@@ -854,10 +878,12 @@ class _TrunkFn(torch.autograd.Function):
                         # expanding 1x1 layer of the first stage: both gradients from one pass over (gl, cl)
                         grads[last + ".weight"], g2, part, chunks = K.conv3_bwd(gl, cl, bl, c2, f2, wt_of(last))
                     else:
-                        fwgrad(last, gl, cl, bl, c2, f2, 1, 0)
+                        d3 = draw_of(gl, cl, bl) if dsep else None
+                        fwgrad(last, gl, cl, bl, c2, f2, 1, 0, d=d3)
                         fcap(last, last_bn, gl, cl, bl, dres=gl.clone() if cap is not None else None)
                         g2, part, chunks = fdgrad(last, gl, cl, bl, c2.shape, 1, 0, ep=(c2, None, f2, True),
-                                                  ep_keep=recompute_keep(c2, f2))
+                                                  ep_keep=recompute_keep(c2, f2), d=d3)
+                        del d3
                     b2 = fin_bwd(pre + ".bn2", part, chunks, 2, c2, f2)
                     planes1 = 2
                     if rec.get("mid_sep"):
@@ -896,7 +922,8 @@ class _TrunkFn(torch.autograd.Function):
                                               ep_keep=recompute_keep(c1, f1))
                     c1_stride, c1_pad = s, 1
                 b1 = fin_bwd(pre + ".bn1", part, chunks, planes1 if bott else 2, c1, f1)
-                fwgrad(pre + ".conv1", g1, c1, b1, xin, None, c1_stride, c1_pad)
+                d1 = draw_of(g1, c1, b1) if dsep else None
+                fwgrad(pre + ".conv1", g1, c1, b1, xin, None, c1_stride, c1_pad, d=d1)
                 fcap(pre + ".conv1", pre + ".bn1", g1, c1, b1)
                 # block-input gradient: (downsample branch | identity) first, conv1's data gradient accumulated last so that
                 # its epilogue sees the complete gradient of the block below's output
@@ -904,13 +931,16 @@ class _TrunkFn(torch.autograd.Function):
                     cd, fd = rec["cd"], rec["fd"]
                     _, partd, chunksd, planesd = _bn_bwd_reduce(K, gl, None, cd, fd, want_g=False)
                     bd = fin_bwd(pre + ".downsample.1", partd, chunksd, planesd, cd, fd)
-                    fwgrad(pre + ".downsample.0", gl, cd, bd, xin, None, s, 0)
+                    dd = draw_of(gl, cd, bd) if dsep else None
+                    fwgrad(pre + ".downsample.0", gl, cd, bd, xin, None, s, 0, d=dd)
                     fcap(pre + ".downsample.0", pre + ".downsample.1", gl, cd, bd)
-                    dx = fdgrad(pre + ".downsample.0", gl, cd, bd, xin.shape, s, 0)      # full cover (zero fill off-lattice)
+                    dx = fdgrad(pre + ".downsample.0", gl, cd, bd, xin.shape, s, 0, d=dd)      # full cover (zero fill off-lattice)
+                    del dd
                 else:
                     dx = gl
                 r = fdgrad(pre + ".conv1", g1, c1, b1, xin.shape, c1_stride, c1_pad, out=dx, accumulate=True, ep=ep_lo,
-                           ep_keep=keep_lo)
+                           ep_keep=keep_lo, d=d1)
+                del d1
                 grad_in = ("plain", r) if ep_lo is None else ("masked", r[0], r[1], r[2], 2)
                 del rec, saved[pre]
                 if bi == 0 or T.blocks[bi - 1]["name"].split(".")[0] != pre.split(".")[0]:

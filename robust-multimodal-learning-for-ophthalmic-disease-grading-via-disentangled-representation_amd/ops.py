@@ -396,7 +396,7 @@ def conv2d_wgrad_bn(g, yraw, bcoef, x, x_fcoef, w_shape, stride=1, pad=0):
     ws = torch.empty(nbytes // 4, device=g.device, dtype=torch.float32)
     _launch_timed("conv_wgrad", 2.0 * N * Ho * Wo * Co * KH * KW * Ci, "edrl_conv2d_nhwc_wgrad_bn_f32", P(g), P(yraw), P(bcoef),
                   P(x), P(x_fcoef), P(out), P(ws), nbytes, N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad, 0,
-                  nbytes=4.0 * (2 * g.numel() + x.numel() + out.numel()))
+                  nbytes=4.0 * ((2 if yraw is not None else 1) * g.numel() + x.numel() + out.numel()))
     return out
 
 
