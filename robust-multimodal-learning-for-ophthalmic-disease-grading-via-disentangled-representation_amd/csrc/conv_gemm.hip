@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution / linear kernels on the gfx950 fp32 matrix cores.
+// Implicit-GEMM convolution / linear kernels for fp32 tensors on the gfx950 matrix cores.
 //
 // Three contractions cover every conv and Linear on the EDRL hot path
 // (reference call sites
@@ -11,14 +11,15 @@
 //       A Linear is the 1x1 case (OH=OW=1, rows = tokens).
 //   wgrad  (TN):            dW[co][k] = sum_pix dY[pix][co] * Xcol[pix][k]   (split-K over pixels)
 //
-// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain; 64 FLOP/clk/SIMD).
+// Matrix instruction.  Shipped (EDRL_F32_SPLIT, below): v_mfma_f32_32x32x16_bf16 over an EXACT three-way bf16 split of both fp32
+// operands, six products per fp32 product, fp32 accumulation -- the bf16 pipe is 16x the fp32 pipe on this chip.  With
+// -DEDRL_F32_SPLIT=0 (libedrl_hip_f32mfma.so) and on the generic (non-FAST) paths: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD).
 // Block = 256 threads = 2x2 waves; wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles.
-// K-contiguous operands are staged to LDS as [row][BK+4] and read with
-// ds_read_b128 (conflict-free at stride 36 dwords): one read feeds 4 MFMA
-// k-steps, lane half h taking k = 8*kc + 4*h + j.  Row-contiguous operands
-// (wgrad) are staged as [k][row] and read with ds_read_b32.
-// Global->LDS is register staged and double buffered (one barrier per K tile):
-// tile t+1's loads are issued before tile t's MFMAs and written after them.
+// fp32-MFMA form: K-contiguous operands are staged to LDS as [row][16] (XOR-swizzled 16-byte chunks) and read with ds_read_b128:
+// one read feeds 4 MFMA k-steps, lane half h taking k = 8*kc + 4*h + j; row-contiguous operands (wgrad) as [k][row], read with
+// ds_read_b32.  Split form: three bf16 planes per operand, see SPL / SPLW in the kernels.
+// Global->LDS is register staged and double buffered (one barrier per K tile): the next tiles' loads are issued before the
+// running tile's MFMAs and written after them.
 #include "edrl_common.h"
 #include <atomic>
 #include <mutex>
