@@ -49,6 +49,9 @@
 #ifndef EDRL_F32_SPLIT
 #define EDRL_F32_SPLIT 1      // 0: fp32 MFMA (libedrl_hip_f32mfma.so is this file compiled with -DEDRL_F32_SPLIT=0)
 #endif
+#ifndef EDRL_F32_SPLIT_ATR2_LEAN
+#define EDRL_F32_SPLIT_ATR2_LEAN 1  // 1: the ATR 2 variants without the accumulating epilogue run a register-lean K loop at 3 per CU
+#endif
 #ifndef EDRL_F32_SPLIT_OCC_EPI2
 #define EDRL_F32_SPLIT_OCC_EPI2 3   // ... of the plain-operand data gradient with the sign-byte epilogue
 #endif
@@ -61,7 +64,8 @@
 // workgroups per CU of a gather-kernel variant: the split K loop keeps two register sets of operand loads in flight
 constexpr int edrl_gather_occ(int bkt, bool fast, bool buf, int atr, int occ, int epi = 0) {
   if (!(EDRL_F32_SPLIT != 0 && bkt == 16 && fast && buf)) return occ;
-  const int cap = atr == 2 ? EDRL_F32_SPLIT_OCC_ATR2 : (epi == 2 ? EDRL_F32_SPLIT_OCC_EPI2 : EDRL_F32_SPLIT_OCC);
+  const int cap = atr == 2 ? ((EDRL_F32_SPLIT_ATR2_LEAN != 0 && epi != 2) ? 3 : EDRL_F32_SPLIT_OCC_ATR2)
+                           : (epi == 2 ? EDRL_F32_SPLIT_OCC_EPI2 : EDRL_F32_SPLIT_OCC);
   return occ > cap ? cap : occ;
 }
 typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
@@ -773,6 +777,45 @@ void conv_gather_f32_v2_kernel(
       sp_finish(std::integral_constant<int, P ^ 1>{}, P ^ 1);
       __syncthreads();
     };
+    if constexpr (EDRL_F32_SPLIT_ATR2_LEAN != 0 && ATR == 2 && EPI != 2) {
+      // Register-lean form for the variants that form d_raw in the operand load: ONE register set (loads one tile ahead), weight
+      // fragments single-buffered -- 150 registers instead of 201-207, so 3 workgroups per CU instead of 2: -2 % over the
+      // ResNet-50 layers, -5 % on the 1x1 layers of stages 3-4 (profiles/r05_f32_split_occ_ab.txt).  The accumulating epilogue
+      // (EPI 2) spills at 3 per CU and loses 12 %: it keeps the two-set loop at 2.
+      const std::integral_constant<int, 0> S0{};
+      sp_load(S0);
+      load_params();
+      sp_finish(S0, 0);
+      __syncthreads();
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        advance();
+        load_params();
+        sp_load(S0);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* pa = (const char*)smem + buf * (BM * 96) + (wm0 + li) * 32 + hs;
+        const char* pb = (const char*)smem + 2 * BM * 96 + buf * (BN * 96) + (wn0 + li) * 32 + hs;
+        sp_bf16x8 fa[3][TM], fb[TN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const sp_bf16x8*>(pa + p * (BM * 32) + i * 1024);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const sp_bf16x8*>(pb + q * (BN * 32) + j * 1024);
+#pragma unroll
+          for (int p = 2 - q; p >= 0; --p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        sp_finish(S0, buf ^ 1);
+        __syncthreads();
+      }
+    } else {
     sp_load(std::integral_constant<int, 0>{});
     load_params();
     sp_finish(std::integral_constant<int, 0>{}, 0);
@@ -782,6 +825,7 @@ void conv_gather_f32_v2_kernel(
     for (int kt = kt0; kt < kt1; kt += 2) {
       sp_iter(std::integral_constant<int, 0>{});
       if (kt + 1 < kt1) sp_iter(std::integral_constant<int, 1>{});
+    }
     }
   } else {
 #pragma unroll
