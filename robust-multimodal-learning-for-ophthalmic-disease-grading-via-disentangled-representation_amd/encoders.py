@@ -179,6 +179,23 @@ def _dbg_draw(g, raw, bc):
 # Kernel sets: the trunk's forward/backward schedule (_TrunkFn) is written once; what differs between the fp32 trunk (C1/C3)
 # and the bf16 trunk (C2/C4: bf16 activations / gradients and bf16 MFMA convs, fp32 BatchNorm statistics, fp32 weights and
 # weight gradients, fp32 stem) is which launchers it calls.
+_ZERO_C = {}
+
+
+def _act_coef(K, fc):
+    """(mean, shift) operands of edrl_bn_apply_mx for a materialised activation relu(bn(raw)) inside a fused block.  fp32 trunk:
+    (0, shift2), so that the pass forms fma(x, scale, shift2) -- the single rounding the conv kernels' operand loads and epilogues
+    use (edrl_bn_pre2) -- and a unit takes the same ReLU decisions, bit for bit, whether its activation is materialised (mid_sep,
+    wide blocks) or formed in the consumer's operand load.  bf16 trunk: (mean, shift) as before (its rounding points differ)."""
+    if K.mx != 0:
+        return fc[0], fc[3]
+    C = fc.shape[1]
+    z = _ZERO_C.get((C, fc.device))
+    if z is None:
+        z = _ZERO_C[(C, fc.device)] = torch.zeros(C, device=fc.device, dtype=torch.float32)
+    return z, fc[4]
+
+
 def _f32_split_build():
     """Does the loaded library form fp32 products as bf16x3 splits (include/edrl_hip.h edrl_f32_contraction_split)?  Decides the
     default block policy of the fp32 trunk only (the fp32-MFMA build is best all-fused)."""
@@ -515,7 +532,8 @@ class _TrunkFn(torch.autograd.Function):
             M = raw.numel() // C
             act = torch.empty_like(raw)
             kb = torch.empty((M, C // 4), device=raw.device, dtype=torch.uint8)
-            ops.call_timed_bytes("bn_apply", M * C * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(raw), K.mx, P(fc[0]), P(fc[2]), P(fc[3]), None,
+            mu_, sh_ = _act_coef(K, fc)
+            ops.call_timed_bytes("bn_apply", M * C * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(raw), K.mx, P(mu_), P(fc[2]), P(sh_), None,
                                  P(act), K.mx, P(kb), M, C, 1)
             return act, kb
 
@@ -551,8 +569,9 @@ class _TrunkFn(torch.autograd.Function):
                         M1 = c1.numel() // C1
                         a1 = torch.empty_like(c1)
                         k1 = torch.empty((M1, C1 // 4), device=c1.device, dtype=torch.uint8)
-                        ops.call_timed_bytes("bn_apply", M1 * C1 * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(c1), K.mx, P(f1[0]), P(f1[2]),
-                                             P(f1[3]), None, P(a1), K.mx, P(k1), M1, C1, 1)
+                        mu_, sh_ = _act_coef(K, f1)
+                        ops.call_timed_bytes("bn_apply", M1 * C1 * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(c1), K.mx, P(mu_), P(f1[2]),
+                                             P(sh_), None, P(a1), K.mx, P(k1), M1, C1, 1)
                         c2, f2 = cf(pre + ".conv2", pre + ".bn2", a1, None, s, 1)
                         # recompute mode: the activated copy and its sign bytes are rebuilt in backward by the same pass
                         keep_a1 = not (T.recompute_out and cap is None)
@@ -892,8 +911,9 @@ class _TrunkFn(torch.autograd.Function):
                             M1 = c1.numel() // C1
                             rec["a1"] = torch.empty_like(c1)
                             rec["k1"] = torch.empty((M1, C1 // 4), device=c1.device, dtype=torch.uint8)
-                            ops.call_timed_bytes("bn_apply", M1 * C1 * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(c1), K.mx, P(f1[0]), P(f1[2]),
-                                                 P(f1[3]), None, P(rec["a1"]), K.mx, P(rec["k1"]), M1, C1, 1)
+                            mu_, sh_ = _act_coef(K, f1)
+                            ops.call_timed_bytes("bn_apply", M1 * C1 * (2 * K.elt + 0.25), "edrl_bn_apply_mx", P(c1), K.mx, P(mu_), P(f1[2]),
+                                                 P(sh_), None, P(rec["a1"]), K.mx, P(rec["k1"]), M1, C1, 1)
                         C2c = c2.shape[-1]
                         d2 = torch.empty_like(c2)
                         ops.call_timed_bytes("bn_draw", c2.numel() * 3 * K.elt, K.draw_name, P(g2), P(c2), P(b2), P(d2), c2.numel() // C2c, C2c)

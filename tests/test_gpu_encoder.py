@@ -108,15 +108,13 @@ def test_trunk_recompute_block_outputs_bit_identical(edrl, dev, depth, in_ch, dt
 @pytest.mark.parametrize("policy", ["all_fused", "wide_from_stage3", "wide_all", "draw_sep_all", "mid_sep_only"])
 def test_fp32_trunk_block_policies_agree(edrl, dev, policy, monkeypatch):
     """The fp32 trunk's block policies (encoders._K32: mid_sep, wide blocks above fuse_max_planes, draw_sep) change WHERE the
-    BatchNorm transforms are applied -- in a conv kernel's operand load / epilogue or in a pass of their own -- not the function.
-    Forward: the output of a ResNet-50 trunk agrees with the shipped default policy to fp32 round-off (<= 2e-4 relative).
-    Backward: a materialised activation is formed as (x - mean)*scale + shift by the elementwise pass and as fma(x, scale, shift2)
-    in a conv's operand load, so a pre-activation within an ulp of zero can take the other side of its ReLU under another policy
-    (each policy is consistent with ITSELF: the backward uses the decision its forward took), and one such flip moves whole
-    upstream gradients by 1e-2 (tests/test_gpu_head.py).  So the gradients are bound as a direction + magnitude check that a wrong
-    kernel path breaks, not as round-off: cosine >= 0.999 and relative difference <= 5e-2 per tensor (measured: draw_sep
-    bit-identical to the operand-load form -- same fma, same K order --; all fused / wide 3e-3 .. 2e-2 on the input gradient).
-    The binding per-unit gradient parity is tests/test_gpu_layerwise.py on the default policy."""
+    BatchNorm transforms are applied -- in a conv kernel's operand load / epilogue or in a pass of their own -- not the function,
+    and not even the bits: a materialised activation is formed with the conv kernels' own single fma (encoders._act_coef), a
+    materialised d_raw with their fma order (edrl_bn_draw_f32), the plain-operand kernels walk K in the same order as the
+    transforming ones, and the epilogues see the same accumulators.  So the forward output, the input gradient and every parameter
+    gradient of a ResNet-50 trunk are BIT-IDENTICAL under every policy -- which checks each separate-pass path (plain-operand data
+    gradient with the sign-byte / recompute epilogues, weight gradient with a plain dY and a transformed X, edrl_bn_draw_f32, the
+    fp32 wide blocks) against the fused kernels it replaces, element for element."""
     K = edrl.encoders._K32
     torch.manual_seed(0)
     trunk = edrl.ResNetTrunk(50, 3).to(dev).train()
@@ -151,11 +149,7 @@ def test_fp32_trunk_block_policies_agree(edrl, dev, policy, monkeypatch):
     def rel(a, b):
         a, b = a.double().flatten(), b.double().flatten()
         return float((a - b).norm() / b.norm().clamp_min(1e-30)), float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
-    fro, cos = rel(got[0], ref[0])
-    assert fro <= 2e-4, f"{policy}: forward output differs from the default policy: rel {fro:.2e}"
-    worst, worst_cos = 0.0, 1.0
+    assert torch.equal(got[0], ref[0]), f"{policy}: forward output differs from the default policy: rel {rel(got[0], ref[0])[0]:.2e}"
     for name, a, b in [("dx", got[1], ref[1])] + [(n, got[2][n], ref[2][n]) for n in ref[2]]:
-        f2, cos = rel(a, b)
-        worst, worst_cos = max(worst, f2), min(worst_cos, cos)
-        assert f2 <= 5e-2 and cos >= 0.999, f"{policy}: {name} differs from the default policy: rel {f2:.2e}, cos {cos:.6f}"
-    print(f"[parity] policy {policy}: forward {fro:.2e}; gradients: worst relative difference {worst:.2e}, worst cosine {worst_cos:.6f}")
+        assert torch.equal(a, b), f"{policy}: {name} differs from the default policy: rel {rel(a, b)[0]:.2e}"
+    print(f"[parity] policy {policy}: output, input gradient and {len(ref[2])} parameter gradients bit-identical to the default policy")
