@@ -183,12 +183,12 @@ _ZERO_C = {}
 
 
 def _act_coef(K, fc):
-    """(mean, shift) operands of edrl_bn_apply_mx for a materialised activation relu(bn(raw)) inside a fused block.  fp32 trunk:
-    (0, shift2), so that the pass forms fma(x, scale, shift2) -- the single rounding the conv kernels' operand loads and epilogues
-    use (edrl_bn_pre2) -- and a unit takes the same ReLU decisions, bit for bit, whether its activation is materialised (mid_sep,
-    wide blocks) or formed in the consumer's operand load.  bf16 trunk: (mean, shift) as before (its rounding points differ)."""
-    if K.mx != 0:
-        return fc[0], fc[3]
+    """(mean, shift) operands of edrl_bn_apply_mx for a materialised activation relu(bn(raw)) inside a fused block: (0, shift2), so
+    that the pass forms fma(x, scale, shift2) -- the single rounding the conv kernels' operand loads and epilogues use
+    (edrl_bn_pre2) -- and a unit takes the same ReLU decisions and stores the same activation, bit for bit, whether it is
+    materialised (mid_sep, wide blocks) or formed in the consumer's operand load.  With (mean, shift) -- (x - mean)*scale + shift,
+    rounds 1-4 -- the policies differed at ulp-level ties, which bf16 storage amplified to 5e-2 .. 1e-1 of the trunk output
+    (tests/test_gpu_encoder.py::test_*_trunk_block_policies_agree: now bit-identical, fp32 and bf16)."""
     C = fc.shape[1]
     z = _ZERO_C.get((C, fc.device))
     if z is None:
